@@ -1,0 +1,161 @@
+/* sy11.h — C-ABI of libsy11.so: the MI355X (gfx950) kernels behind the Spectrogram-YOLOv11 hot path.
+ *
+ * The reference (a fork of Ultralytics 8.3.70) has NO native code and NO FFI on this path: every op is a
+ * stock ATen call issued from Python modules.  Each entry point below therefore names the reference
+ * *Python call site* whose arithmetic it replaces (file:line under /root/reference/ultralytics), which is
+ * what a maintainer would re-bind (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers borrowed from the caller (torch tensors); the library allocates
+ *     nothing persistent and keeps no global state; every call is asynchronous on `stream`
+ *     (a hipStream_t passed as void*), re-entrant per stream, and never synchronises the host;
+ *   - activations are NHWC; a tensor view is (pointer to first used channel, `ld` = elements between
+ *     consecutive pixels), so channel slices of a wider buffer ("concat by pointer") need no copy;
+ *   - conv weights are [Cout][KH][KW][Cin/groups] (= torch OIHW tensor in channels_last memory format);
+ *   - dtype codes: 0 = f32, 1 = f16, 2 = bf16.  Accumulation is always f32;
+ *   - return value: 0 on success, negative sy11_status on error; sy11_last_error() gives the message
+ *     (thread-local).  Shapes/strides are validated on the host BEFORE any launch.
+ */
+#ifndef SY11_H
+#define SY11_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SY11_VERSION 100
+
+enum sy11_status { SY11_OK = 0, SY11_EINVAL = -1, SY11_EUNSUPPORTED = -2, SY11_ELAUNCH = -3 };
+enum sy11_dtype { SY11_F32 = 0, SY11_F16 = 1, SY11_BF16 = 2 };
+
+/* epilogue / behaviour flags for the conv entry points */
+#define SY11_EPI_SILU 1u       /* y = silu(acc + bias)                                   */
+#define SY11_EPI_ACCUM 2u      /* y += acc (gradient accumulation into an existing view)  */
+#define SY11_EPI_OUT_F32 4u    /* y is f32 whatever desc.dtype says (Detect logits)       */
+
+typedef struct sy11_conv_desc {
+  int32_t dtype;               /* element type of x, w, (y)                                  */
+  int32_t B, IH, IW, C;        /* input: batch, height, width, channels CONSUMED              */
+  int32_t x_ld;                /* input pixel stride (elements), >= C                          */
+  int32_t OH, OW, N;           /* output: height, width, channels PRODUCED                     */
+  int32_t y_ld;                /* output pixel stride (elements), >= N                         */
+  int32_t KH, KW, SH, SW, PH, PW, DH, DW;
+  int32_t groups;              /* 1, or == C == N (depthwise)                                  */
+  uint32_t flags;              /* SY11_EPI_*                                                   */
+} sy11_conv_desc;
+
+int sy11_version(void);
+const char* sy11_last_error(void);
+
+/* ---- convolution (replaces nn.Conv2d inside Conv.forward / forward_fuse, nn/modules/conv.py:79-83,
+ *      and the bare nn.Conv2d heads of Detect, nn/modules/head.py:44-55) -------------------------------- */
+
+/* y[b,oy,ox,n] = sum_{r,s,c} x[b, oy*SH-PH+r*DH, ox*SW-PW+s*DW, c] * w[n,r,s,c]  (+bias[n]) (silu)
+ * groups==1: implicit-GEMM on MFMA.  groups==C==N: direct depthwise kernel.
+ * stat_sum/stat_sq (f32[N], may be NULL): per-channel sum and sum of squares of the f32 accumulators are
+ * atomically ADDED (BatchNorm batch statistics of F.batch_norm(training=True), conv.py:81).               */
+int sy11_conv2d_fwd(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                    float* stat_sum, float* stat_sq, void* stream);
+
+/* dx = conv_transpose(dy, w): gradient wrt the input of the conv described by `d`
+ * (autograd of nn.Conv2d, fired by loss.backward() at engine/trainer.py:388).
+ * `dy` has pixel stride dy_ld, `dx` pixel stride d->x_ld.  wt is the tap-transposed filter made by
+ * sy11_weight_transpose: [C][KH*KW][N] for groups==1 (ignored for depthwise: pass w).
+ * SY11_EPI_ACCUM in d->flags adds into dx instead of overwriting it.                                      */
+int sy11_conv2d_dgrad(const sy11_conv_desc* d, const void* dy, int32_t dy_ld, const void* wt, void* dx, void* stream);
+
+/* dw[n,r,s,c] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, oy*SH-PH+r*DH, ox*SW-PW+s*DW, c]   (dw is ALWAYS f32 and is
+ * accumulated into: zero it for a fresh gradient).                                                         */
+int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const void* dy, int32_t dy_ld, float* dw, void* stream);
+
+/* wt[c][t][n] = w[n][t][c]  (t = r*KW+s), same dtype; feeds sy11_conv2d_dgrad                               */
+int sy11_weight_transpose(int32_t dtype, int32_t N, int32_t T, int32_t C, const void* w, void* wt, void* stream);
+
+/* first layer: x is the caller's NCHW f32 image (B,3,H,W) in [0,1] (detect/train.py:59 output); y NHWC.    */
+int sy11_stem_conv_fwd(const sy11_conv_desc* d, const float* x_nchw, const void* w, const float* bias, void* y,
+                       float* stat_sum, float* stat_sq, void* stream);
+int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw, const void* dy, int32_t dy_ld, float* dw,
+                         void* stream);
+
+/* ---- BatchNorm (+SiLU, + residual) around the conv: nn.BatchNorm2d + nn.SiLU in Conv.forward
+ *      (nn/modules/conv.py:81), eps/momentum from utils/torch_utils.py:417-418, residual of Bottleneck
+ *      (nn/modules/block.py:725) ------------------------------------------------------------------------- */
+
+/* from sum/sumsq over `count` pixels: mean, rstd (saved for backward), scale = gamma*rstd,
+ * shift = beta - mean*scale, and the running-stat update (unbiased var, momentum).                          */
+int sy11_bn_finalize(int32_t C, double count, const float* stat_sum, const float* stat_sq, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                     float* mean, float* rstd, float* scale, float* shift, void* stream);
+
+/* z = act(y*scale[c] + shift[c]) (+ res);  y,z,res: M pixels x C channels with their own pixel strides      */
+int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const float* scale,
+                    const float* shift, int32_t silu, const void* res, int32_t res_ld, void* z, int32_t z_ld,
+                    void* stream);
+
+/* backward, pass 1: g = dz * act'(y*scale+shift);  sum_g[c] += sum g;  sum_gx[c] += sum g * xhat            */
+int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
+                           int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
+                           const float* shift, int32_t silu, float* sum_g, float* sum_gx, void* stream);
+/* backward, pass 2: dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); also dgamma += sum_gx, dbeta += sum_g     */
+int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
+                          int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
+                          const float* shift, const float* gamma, int32_t silu, const float* sum_g,
+                          const float* sum_gx, void* dy, int32_t dy_ld, float* dgamma, float* dbeta, void* stream);
+/* SiLU backward only (fused-BN / bias epilogues): dy = dz * silu'(pre) where pre = y (pre-activation)       */
+
+/* ---- data movement inside the graph --------------------------------------------------------------------- */
+/* dst[m, 0:C] (= | +=) src[m, 0:C] with independent pixel strides: torch.cat / chunk (conv.py:1821,
+ * block.py:466-468) and residual-gradient accumulation.                                                     */
+int sy11_copy2d(int32_t dtype, int64_t M, int32_t C, const void* src, int32_t src_ld, void* dst, int32_t dst_ld,
+                int32_t accumulate, void* stream);
+/* nn.Upsample(None, 2, "nearest") (cfg/models/11/yolo11.yaml:34,38) written straight into a concat slice    */
+int sy11_upsample2x_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, int32_t x_ld,
+                        void* y, int32_t y_ld, void* stream);
+int sy11_upsample2x_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
+                        void* dx, int32_t dx_ld, int32_t accumulate, void* stream);
+/* nn.MaxPool2d(5, 1, 2) (SPPF, nn/modules/block.py:192,197); idx[m,c] = window position (0..24) of the
+ * first maximum in row-major scan order (ATen max_pool2d_with_indices tie rule).                            */
+int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, int32_t x_ld,
+                      void* y, int32_t y_ld, uint8_t* idx, void* stream);
+int sy11_maxpool5_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
+                      const uint8_t* idx, void* dx, int32_t dx_ld, int32_t accumulate, void* stream);
+/* NCHW f32 <-> NHWC dtype boundary conversions (module-level drop-in keeps NCHW-shaped tensors)             */
+int sy11_nchw_to_nhwc(int32_t dtype, int32_t B, int32_t C, int32_t H, int32_t W, const float* x, void* y,
+                      int32_t y_ld, void* stream);
+int sy11_cast(int32_t src_dtype, int32_t dst_dtype, int64_t n, const void* src, void* dst, void* stream);
+
+/* ---- C2PSA attention core: softmax(q^T k * scale) applied to v (nn/modules/block.py:1925-1931) ---------- */
+/* qkv: (B, N, heads*(2*kd+hd)) NHWC pixels, per head [q(kd) k(kd) v(hd)];  o: (B, N, heads*hd);
+ * p (f32, B*heads*N*N) receives the attention probabilities (kept for backward).                            */
+int sy11_attention_fwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
+                       int32_t qkv_ld, void* o, int32_t o_ld, float* p, void* stream);
+int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
+                       int32_t qkv_ld, const float* p, const void* d_o, int32_t do_ld, void* dqkv, int32_t dqkv_ld,
+                       float* workspace, void* stream);
+
+/* ---- Detect decode + NMS (nn/modules/head.py:100-131; utils/ops.py:181-332 + torchvision.ops.nms) ------- */
+/* maps: 3 NHWC f32 maps (B,H_l,W_l,64+nc); out: (B, 4+nc, A) f32 exactly as Detect._inference returns it.   */
+int sy11_detect_decode(int32_t B, int32_t nc, int32_t nl, const float* const* maps, const int32_t* hs,
+                       const int32_t* ws, const float* strides, float* out, void* stream);
+/* greedy NMS over n candidate boxes ALREADY sorted by (score desc, index asc): keep[i] in {0,1}.
+ * boxes: (n,4) xyxy f32 (class offset already added).  workspace: n*ceil(n/64) uint64 words.               */
+int sy11_nms_sorted(int32_t n, const float* boxes, float iou_thres, uint64_t* workspace, uint8_t* keep,
+                    void* stream);
+size_t sy11_nms_workspace_bytes(int32_t n);
+
+/* ---- IQ -> STFT -> power -> mel -> log producer (no reference code: README.md:7; spec in DESIGN.md) ------ */
+/* iq: (B, L) interleaved complex64; db: (B, n_mel, n_frames) f32 dB; minmax: (B,2) f32 [min,max] per image
+ * (must be pre-filled with +inf/-inf by the caller or by sy11_stft_minmax_init).                            */
+int sy11_stft_logmel(int32_t B, int32_t L, int32_t n_fft, int32_t hop, int32_t n_frames, int32_t n_mel,
+                     const float* iq, const float* window, const int32_t* mel_start, const float* mel_w,
+                     int32_t mel_taps, float* db, float* minmax, void* stream);
+int sy11_stft_minmax_init(int32_t B, float* minmax, void* stream);
+/* img[b,c,f,t] = (db-min)/(max-min), c = 0..2, NCHW f32 (what preprocess_batch hands the model)             */
+int sy11_stft_normalize(int32_t B, int32_t n_mel, int32_t n_frames, const float* db, const float* minmax,
+                        float* img_nchw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SY11_H */

@@ -1,0 +1,133 @@
+// detect.hip — Detect._inference decode (DFL expectation + dist2bbox + sigmoid) and greedy NMS for gfx950.
+//
+// decode: replaces nn/modules/head.py:100-131 (+ block.py:80 DFL, utils/tal.py:349-358 dist2bbox): one thread per
+// (image, anchor); reads the NHWC f32 head maps, writes the reference's (B, 4+nc, A) layout coalesced over anchors.
+// nms: replaces torchvision.ops.nms as called from utils/ops.py:312.  Candidates arrive sorted (score desc, index asc);
+// kernel 1 builds the n x n/64 suppression bit matrix (IoU > thr, strict) with one wave ballot per 64 columns,
+// kernel 2 is the serial greedy sweep held by ONE wave (removed-mask words in LDS), so the kept set is exactly the
+// sequential algorithm's: bit-exact indices.  IoU arithmetic is plain f32 without contraction so it matches the oracle.
+#include "common.h"
+
+struct DecodeArgs {
+  const float* maps[8];
+  int hs[8], ws[8], a0[8];
+  float strides[8];
+  int B, nc, nl, A;
+  float* out;
+};
+
+__global__ __launch_bounds__(256) void detect_decode_kernel(const DecodeArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.B * a.A) return;
+  const int b = idx / a.A, an = idx - b * a.A;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < a.nl && an >= a.a0[i]) l = i;
+  const int loc = an - a.a0[l];
+  const int W = a.ws[l], H = a.hs[l];
+  const int gy = loc / W, gx = loc - gy * W;
+  const int no = 64 + a.nc;
+  const float* src = a.maps[l] + ((long)b * H * W + loc) * no;
+  float d[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[16], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { v[k] = src[s * 16 + k]; mx = fmaxf(mx, v[k]); }
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const float e = expf(v[k] - mx); den += e; num += e * (float)k; }
+    d[s] = num / den;
+  }
+  const float ax = gx + 0.5f, ay = gy + 0.5f, st = a.strides[l];
+  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+  float* o = a.out + (long)b * (4 + a.nc) * a.A + an;
+  o[0] = (x1 + x2) * 0.5f * st;
+  o[(long)a.A] = (y1 + y2) * 0.5f * st;
+  o[2L * a.A] = (x2 - x1) * st;
+  o[3L * a.A] = (y2 - y1) * st;
+  for (int c = 0; c < a.nc; ++c) o[(long)(4 + c) * a.A] = 1.f / (1.f + expf(-src[64 + c]));
+}
+
+extern "C" int sy11_detect_decode(int32_t B, int32_t nc, int32_t nl, const float* const* maps, const int32_t* hs,
+                                  const int32_t* ws, const float* strides, float* out, void* stream) {
+  SY11_REQUIRE(B > 0 && nc > 0 && nl > 0 && nl <= 8 && maps && hs && ws && strides && out, "detect_decode: bad argument");
+  DecodeArgs a{};
+  int A = 0;
+  for (int i = 0; i < nl; ++i) {
+    SY11_REQUIRE(maps[i] && hs[i] > 0 && ws[i] > 0, "detect_decode: bad level %d", i);
+    a.maps[i] = maps[i]; a.hs[i] = hs[i]; a.ws[i] = ws[i]; a.strides[i] = strides[i]; a.a0[i] = A;
+    A += hs[i] * ws[i];
+  }
+  SY11_REQUIRE((long)B * A < (1L << 31), "detect_decode: too many anchors");
+  a.B = B; a.nc = nc; a.nl = nl; a.A = A; a.out = out;
+  hipLaunchKernelGGL(detect_decode_kernel, dim3(cdiv((long)B * A, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  SY11_LAUNCH_CHECK("detect_decode");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ NMS
+__global__ __launch_bounds__(64) void nms_mask_kernel(int n, int nw, const float* __restrict__ boxes, float thr, uint64_t* __restrict__ mask) {
+#pragma clang fp contract(off)
+  // block (cb, rb): rows rb*64..+63 (one per lane), column word cb
+  const int cb = blockIdx.x, rb = blockIdx.y;
+  if (cb < rb) return;   // only j > i can be suppressed by i; words left of the diagonal stay zero (pre-cleared)
+  __shared__ float cbx[64][4];
+  const int lane = threadIdx.x;
+  const int cj = cb * 64 + lane;
+  if (cj < n) { cbx[lane][0] = boxes[cj * 4]; cbx[lane][1] = boxes[cj * 4 + 1]; cbx[lane][2] = boxes[cj * 4 + 2]; cbx[lane][3] = boxes[cj * 4 + 3]; }
+  __syncthreads();
+  const int i = rb * 64 + lane;
+  if (i >= n) return;
+  const float x1 = boxes[i * 4], y1 = boxes[i * 4 + 1], x2 = boxes[i * 4 + 2], y2 = boxes[i * 4 + 3];
+  const float ai = (x2 - x1) * (y2 - y1);
+  uint64_t bits = 0;
+  const int jmax = min(64, n - cb * 64);
+  for (int j = 0; j < jmax; ++j) {
+    const int gj = cb * 64 + j;
+    if (gj <= i) continue;
+    const float xx1 = fmaxf(x1, cbx[j][0]), yy1 = fmaxf(y1, cbx[j][1]);
+    const float xx2 = fminf(x2, cbx[j][2]), yy2 = fminf(y2, cbx[j][3]);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float aj = (cbx[j][2] - cbx[j][0]) * (cbx[j][3] - cbx[j][1]);
+    const float iou = inter / (ai + aj - inter);
+    if (iou > thr) bits |= (1ull << j);
+  }
+  mask[(long)i * nw + cb] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_sweep_kernel(int n, int nw, const uint64_t* __restrict__ mask, uint8_t* __restrict__ keep) {
+  extern __shared__ uint64_t removed[];
+  const int lane = threadIdx.x;
+  for (int w = lane; w < nw; w += 64) removed[w] = 0;
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    const uint64_t r = removed[i >> 6];            // wave-uniform read
+    const bool dead = (r >> (i & 63)) & 1;
+    if (lane == 0) keep[i] = dead ? 0 : 1;
+    if (!dead) {
+      const uint64_t* row = mask + (long)i * nw;
+      for (int w = (i >> 6) + lane; w < nw; w += 64) removed[w] |= row[w];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" size_t sy11_nms_workspace_bytes(int32_t n) { return n <= 0 ? 0 : (size_t)n * ((n + 63) / 64) * sizeof(uint64_t); }
+
+extern "C" int sy11_nms_sorted(int32_t n, const float* boxes, float iou_thres, uint64_t* workspace, uint8_t* keep, void* stream) {
+  SY11_REQUIRE(n >= 0, "nms_sorted: negative n");
+  if (n == 0) return SY11_OK;
+  SY11_REQUIRE(boxes && workspace && keep, "nms_sorted: null pointer");
+  SY11_REQUIRE(n <= 65535 * 64, "nms_sorted: n too large");
+  const int nw = (n + 63) / 64;
+  SY11_REQUIRE((size_t)nw * 8 <= 64 * 1024, "nms_sorted: n=%d exceeds the LDS removed-mask", n);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, sy11_nms_workspace_bytes(n), st) != hipSuccess) SY11_FAIL(SY11_ELAUNCH, "nms_sorted: memset failed");
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, st, n, nw, boxes, iou_thres, workspace);
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), (size_t)nw * 8, st, n, nw, (const uint64_t*)workspace, keep);
+  SY11_LAUNCH_CHECK("nms_sorted");
+  return SY11_OK;
+}

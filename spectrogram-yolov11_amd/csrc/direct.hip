@@ -1,0 +1,451 @@
+// direct.hip — direct (non-GEMM) convolutions for gfx950: depthwise KxK (Detect cls branch, attention `pe`) and the
+// 3-channel stem.  Both are HBM/L2-bound (depthwise: 4.5 FLOP/B; stem: K = 27), so no MFMA: a thread owns a fixed
+// 16-byte channel vector, keeps its filter taps in registers and walks pixels; neighbouring taps are L1/L2 hits.
+#include "common.h"
+
+template <typename T, int VEC>
+__device__ __forceinline__ void dvload(const T* p, float* f) {
+  if constexpr (VEC == 1) {
+    f[0] = ElemTraits<T>::to_f(*p);
+  } else {
+    typedef T vt __attribute__((ext_vector_type(VEC)));
+    const vt v = *(const vt*)p;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = ElemTraits<T>::to_f(v[i]);
+  }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void dvstore(T* p, const float* f) {
+  if constexpr (VEC == 1) {
+    *p = ElemTraits<T>::from_f(f[0]);
+  } else {
+    typedef T vt __attribute__((ext_vector_type(VEC)));
+    vt v;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = ElemTraits<T>::from_f(f[i]);
+    *(vt*)p = v;
+  }
+}
+
+struct DwArgs {
+  const void* x; const void* w; void* y; const float* bias; float* stat_sum; float* stat_sq;
+  int B, IH, IW, OH, OW, C, x_ld, y_ld;
+  int KH, KW, SH, SW, PH, PW, DH, DW;
+  unsigned flags;
+  int cpv, rows_pb;
+  long rows_per_block;
+};
+
+// MAXT = taps kept in registers (9 for 3x3)
+template <typename T, int VEC, int MAXT>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwArgs a) {
+  __shared__ float red[2][256][VEC];
+  const int cw = a.cpv < 256 ? a.cpv : 256;
+  const int cl = threadIdx.x % cw, cv = blockIdx.y * 256 + cl, rsub = threadIdx.x / cw;
+  const bool active = cv < a.cpv && rsub < a.rows_pb;
+  const int c = cv * VEC;
+  const int Tn = a.KH * a.KW;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+  if (active) {
+    float wr[MAXT][VEC], bv[VEC];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) wr[t][i] = t < Tn ? ElemTraits<T>::to_f(((const T*)a.w)[(long)(c + i) * Tn + t]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) bv[i] = a.bias ? a.bias[c + i] : 0.f;
+    const long M = (long)a.B * a.OH * a.OW;
+    const long m0 = (long)blockIdx.x * a.rows_per_block;
+    const long m1 = m0 + a.rows_per_block < M ? m0 + a.rows_per_block : M;
+    const bool silu = a.flags & SY11_EPI_SILU;
+    for (long m = m0 + rsub; m < m1; m += a.rows_pb) {
+      const int ox = (int)(m % a.OW);
+      const long q = m / a.OW;
+      const int oy = (int)(q % a.OH), b = (int)(q / a.OH);
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int r = t / a.KW, s = t - r * a.KW;
+        const int iy = oy * a.SH - a.PH + r * a.DH, ix = ox * a.SW - a.PW + s * a.DW;
+        if (t < Tn && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) {
+          float v[VEC];
+          dvload<T, VEC>((const T*)a.x + ((long)(b * a.IH + iy) * a.IW + ix) * a.x_ld + c, v);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += v[i] * wr[t][i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        s1[i] += acc[i];
+        s2[i] += acc[i] * acc[i];
+        float v = acc[i] + bv[i];
+        acc[i] = silu ? silu_f(v) : v;
+      }
+      dvstore<T, VEC>((T*)a.y + m * a.y_ld + c, acc);
+    }
+  }
+  if (a.stat_sum) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
+    __syncthreads();
+    if (rsub == 0 && cv < a.cpv) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float p = 0.f, q = 0.f;
+        for (int r = 0; r < a.rows_pb; ++r) { p += red[0][r * cw + cl][i]; q += red[1][r * cw + cl][i]; }
+        atomicAdd(a.stat_sum + c + i, p);
+        atomicAdd(a.stat_sq + c + i, q);
+      }
+    }
+  }
+}
+
+// dx[p][c] (+)= sum_t dy[(p + P - t*D)/S][c] * w[c][t]
+template <typename T, int VEC, int MAXT>
+__global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const DwArgs a, int dy_ld) {
+  const int cw = a.cpv < 256 ? a.cpv : 256;
+  const int cv = blockIdx.y * 256 + (threadIdx.x % cw), rsub = threadIdx.x / cw;
+  if (cv >= a.cpv || rsub >= a.rows_pb) return;
+  const int c = cv * VEC;
+  const int Tn = a.KH * a.KW;
+  float wr[MAXT][VEC];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) wr[t][i] = t < Tn ? ElemTraits<T>::to_f(((const T*)a.w)[(long)(c + i) * Tn + t]) : 0.f;
+  const long M = (long)a.B * a.IH * a.IW;
+  const bool accum = a.flags & SY11_EPI_ACCUM;
+  for (long m = (long)blockIdx.x * a.rows_pb + rsub; m < M; m += (long)gridDim.x * a.rows_pb) {
+    const int ix = (int)(m % a.IW);
+    const long q = m / a.IW;
+    const int iy = (int)(q % a.IH), b = (int)(q / a.IH);
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int r = t / a.KW, s = t - r * a.KW;
+      const int ny = iy + a.PH - r * a.DH, nx = ix + a.PW - s * a.DW;
+      const int oy = ny / a.SH, ox = nx / a.SW;
+      const bool ok = t < Tn && ny >= 0 && nx >= 0 && (ny % a.SH) == 0 && (nx % a.SW) == 0 && oy < a.OH && ox < a.OW;
+      if (ok) {
+        float g[VEC];
+        dvload<T, VEC>((const T*)a.x + ((long)(b * a.OH + oy) * a.OW + ox) * dy_ld + c, g);   // a.x = dy here
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += g[i] * wr[t][i];
+      }
+    }
+    T* dp = (T*)a.y + m * a.x_ld + c;                                                        // a.y = dx, stride x_ld
+    if (accum) {
+      float o[VEC];
+      dvload<T, VEC>(dp, o);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += o[i];
+    }
+    dvstore<T, VEC>(dp, acc);
+  }
+}
+
+// dw[c][t] += sum_m dy[m][c] * x[pix(m,t)][c]
+template <typename T, int VEC, int MAXT>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int dy_ld, float* dw) {
+  __shared__ float red[256][VEC + 1];
+  const int cw = a.cpv < 256 ? a.cpv : 256;
+  const int cl = threadIdx.x % cw, cv = blockIdx.y * 256 + cl, rsub = threadIdx.x / cw;
+  const bool active = cv < a.cpv && rsub < a.rows_pb;
+  const int c = cv * VEC;
+  const int Tn = a.KH * a.KW;
+  float acc[MAXT][VEC];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+  if (active) {
+    const long M = (long)a.B * a.OH * a.OW;
+    const long m0 = (long)blockIdx.x * a.rows_per_block;
+    const long m1 = m0 + a.rows_per_block < M ? m0 + a.rows_per_block : M;
+    for (long m = m0 + rsub; m < m1; m += a.rows_pb) {
+      const int ox = (int)(m % a.OW);
+      const long q = m / a.OW;
+      const int oy = (int)(q % a.OH), b = (int)(q / a.OH);
+      float g[VEC];
+      dvload<T, VEC>((const T*)a.y + m * dy_ld + c, g);                                      // a.y = dy here
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int r = t / a.KW, s = t - r * a.KW;
+        const int iy = oy * a.SH - a.PH + r * a.DH, ix = ox * a.SW - a.PW + s * a.DW;
+        if (t < Tn && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) {
+          float v[VEC];
+          dvload<T, VEC>((const T*)a.x + ((long)(b * a.IH + iy) * a.IW + ix) * a.x_ld + c, v);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[t][i] += g[i] * v[i];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[threadIdx.x][i] = acc[t][i];
+    __syncthreads();
+    if (t < Tn && rsub == 0 && cv < a.cpv) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float p = 0.f;
+        for (int r = 0; r < a.rows_pb; ++r) p += red[r * cw + cl][i];
+        atomicAdd(dw + (long)(c + i) * Tn + t, p);
+      }
+    }
+  }
+}
+
+static int dw_setup(const sy11_conv_desc* d, DwArgs& a, bool& vec, const void* p0, int ld0, const void* p1, int ld1, long M,
+                    int min_rows_per_thread, dim3& grid) {
+  SY11_REQUIRE(d->KH * d->KW <= 9, "depthwise: only up to 9 taps (3x3) are supported");
+  const int esz = dtype_size(d->dtype), ve = 16 / esz;
+  vec = (d->C % ve == 0) && (ld0 % ve == 0) && (ld1 % ve == 0) && !(((uintptr_t)p0 | (uintptr_t)p1) & 15);
+  const int v = vec ? ve : 1;
+  a.B = d->B; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.C = d->C; a.x_ld = d->x_ld; a.y_ld = d->y_ld;
+  a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW; a.DH = d->DH; a.DW = d->DW;
+  a.flags = d->flags;
+  a.cpv = d->C / v;
+  const int cw = a.cpv < 256 ? a.cpv : 256;
+  a.rows_pb = 256 / cw;
+  long nblk = (M + (long)a.rows_pb * min_rows_per_thread - 1) / ((long)a.rows_pb * min_rows_per_thread);
+  if (nblk > 4096) nblk = 4096;
+  if (nblk < 1) nblk = 1;
+  a.rows_per_block = ((M + nblk - 1) / nblk + a.rows_pb - 1) / a.rows_pb * a.rows_pb;
+  nblk = (M + a.rows_per_block - 1) / a.rows_per_block;
+  grid = dim3((unsigned)nblk, cdiv(a.cpv, 256));
+  return SY11_OK;
+}
+
+int sy11_dwconv_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                         float* stat_sum, float* stat_sq, hipStream_t st) {
+  SY11_REQUIRE(x && w && y, "dwconv_fwd: null pointer");
+  SY11_REQUIRE(!(d->flags & (SY11_EPI_ACCUM | SY11_EPI_OUT_F32)), "dwconv_fwd: unsupported epilogue flag");
+  DwArgs a{};
+  bool vec;
+  dim3 grid;
+  int rc = dw_setup(d, a, vec, x, d->x_ld, y, d->y_ld, (long)d->B * d->OH * d->OW, 4, grid);
+  if (rc) return rc;
+  a.x = x; a.w = w; a.y = y; a.bias = bias; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  SY11_DISPATCH_DTYPE(d->dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (vec) hipLaunchKernelGGL((dwconv_fwd_kernel<T, VE, 9>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwconv_fwd_kernel<T, 1, 9>), grid, dim3(256), 0, st, a);
+  });
+  SY11_LAUNCH_CHECK("dwconv_fwd");
+  return SY11_OK;
+}
+
+int sy11_dwconv_dgrad_impl(const sy11_conv_desc* d, const void* dy, int dy_ld, const void* w, void* dx, hipStream_t st) {
+  SY11_REQUIRE(dy && w && dx && dy_ld >= d->N, "dwconv_dgrad: bad argument");
+  DwArgs a{};
+  bool vec;
+  dim3 grid;
+  int rc = dw_setup(d, a, vec, dy, dy_ld, dx, d->x_ld, (long)d->B * d->IH * d->IW, 1, grid);
+  if (rc) return rc;
+  a.x = dy; a.w = w; a.y = dx;
+  SY11_DISPATCH_DTYPE(d->dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (vec) hipLaunchKernelGGL((dwconv_dgrad_kernel<T, VE, 9>), grid, dim3(256), 0, st, a, dy_ld);
+    else hipLaunchKernelGGL((dwconv_dgrad_kernel<T, 1, 9>), grid, dim3(256), 0, st, a, dy_ld);
+  });
+  SY11_LAUNCH_CHECK("dwconv_dgrad");
+  return SY11_OK;
+}
+
+extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, const void* dy, int dy_ld, float* dw, hipStream_t st) {
+  SY11_REQUIRE(x && dy && dw && dy_ld >= d->N && d->x_ld >= d->C, "dwconv_wgrad: bad argument");
+  DwArgs a{};
+  bool vec;
+  dim3 grid;
+  int rc = dw_setup(d, a, vec, x, d->x_ld, dy, dy_ld, (long)d->B * d->OH * d->OW, 32, grid);
+  if (rc) return rc;
+  a.x = x; a.y = (void*)dy;
+  SY11_DISPATCH_DTYPE(d->dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (vec) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, VE, 9>), grid, dim3(256), 0, st, a, dy_ld, dw);
+    else hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 1, 9>), grid, dim3(256), 0, st, a, dy_ld, dw);
+  });
+  SY11_LAUNCH_CHECK("dwconv_wgrad");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stem (Cin = 3, NCHW f32 in)
+// One thread = one output pixel x all N (<= 64) output channels; the 27 x N filter sits in LDS (broadcast reads).
+struct StemArgs {
+  const float* x; const void* w; void* y; const float* bias; float* stat_sum; float* stat_sq;
+  int B, IH, IW, OH, OW, N, y_ld, SH, SW, PH, PW;
+  unsigned flags;
+};
+
+template <typename T, int NMAX>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
+  __shared__ float sw[27][NMAX];
+  __shared__ float red[2][NMAX];
+  for (int i = threadIdx.x; i < 27 * NMAX; i += 256) {
+    const int k = i / NMAX, n = i - k * NMAX;          // k = (r*3+s)*3 + c  (filter layout [n][r][s][c])
+    sw[k][n] = n < a.N ? ElemTraits<T>::to_f(((const T*)a.w)[n * 27 + k]) : 0.f;
+  }
+  if (threadIdx.x < 2 * NMAX) ((float*)red)[threadIdx.x] = 0.f;
+  __syncthreads();
+  const long M = (long)a.B * a.OH * a.OW;
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  float acc[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+  const bool ok = m < M;
+  if (ok) {
+    const int ox = (int)(m % a.OW);
+    const long q = m / a.OW;
+    const int oy = (int)(q % a.OH), b = (int)(q / a.OH);
+    const long plane = (long)a.IH * a.IW;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy * a.SH - a.PH + r;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ix = ox * a.SW - a.PW + s;
+        const bool in = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float v = in ? a.x[((long)b * 3 + c) * plane + (long)iy * a.IW + ix] : 0.f;
+          const int k = (r * 3 + s) * 3 + c;
+#pragma unroll
+          for (int n = 0; n < NMAX; ++n) acc[n] += v * sw[k][n];
+        }
+      }
+    }
+  }
+  const bool silu = a.flags & SY11_EPI_SILU;
+  if (a.stat_sum) {
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      float s1 = ok ? acc[n] : 0.f, s2 = s1 * s1;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0][n], s1); atomicAdd(&red[1][n], s2); }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.N) { atomicAdd(a.stat_sum + threadIdx.x, red[0][threadIdx.x]); atomicAdd(a.stat_sq + threadIdx.x, red[1][threadIdx.x]); }
+  }
+  if (ok) {
+    T* yp = (T*)a.y + m * a.y_ld;
+    for (int n = 0; n < NMAX; ++n) {
+      if (n >= a.N) break;
+      float v = acc[n] + (a.bias ? a.bias[n] : 0.f);
+      yp[n] = ElemTraits<T>::from_f(silu ? silu_f(v) : v);
+    }
+  }
+}
+
+// dW[n][k] += sum_m dy[m][n] * patch[m][k]: stage 64 pixels of dy (64 x N) and patches (64 x 27) in LDS, each thread
+// owns up to 4 (n,k) outputs.
+template <typename T, int NMAX>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, int dy_ld, float* dw, long pix_per_block) {
+  constexpr int BP = 64;
+  constexpr int NOUT = (27 * NMAX + 255) / 256;
+  __shared__ float sdy[BP][NMAX + 1];
+  __shared__ float sp[BP][28];
+  const long M = (long)a.B * a.OH * a.OW;
+  const long m0 = (long)blockIdx.x * pix_per_block;
+  const long m1 = m0 + pix_per_block < M ? m0 + pix_per_block : M;
+  float acc[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
+  const long plane = (long)a.IH * a.IW;
+  for (long mb = m0; mb < m1; mb += BP) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < BP * NMAX; i += 256) {
+      const int p = i / NMAX, n = i - p * NMAX;
+      const long m = mb + p;
+      sdy[p][n] = (m < m1 && n < a.N) ? ElemTraits<T>::to_f(((const T*)a.y)[m * dy_ld + n]) : 0.f;   // a.y = dy
+    }
+    for (int i = threadIdx.x; i < BP * 27; i += 256) {
+      const int p = i / 27, k = i - p * 27;
+      const long m = mb + p;
+      float v = 0.f;
+      if (m < m1) {
+        const int ox = (int)(m % a.OW);
+        const long q = m / a.OW;
+        const int oy = (int)(q % a.OH), b = (int)(q / a.OH);
+        const int c = k % 3, rs = k / 3, r = rs / 3, s = rs - r * 3;
+        const int iy = oy * a.SH - a.PH + r, ix = ox * a.SW - a.PW + s;
+        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) v = a.x[((long)b * 3 + c) * plane + (long)iy * a.IW + ix];
+      }
+      sp[p][k] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      const int id = threadIdx.x + o * 256;
+      if (id < 27 * NMAX) {
+        const int n = id / 27, k = id - n * 27;
+        float s = 0.f;
+#pragma unroll 8
+        for (int p = 0; p < BP; ++p) s += sdy[p][n] * sp[p][k];
+        acc[o] += s;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    const int id = threadIdx.x + o * 256;
+    if (id < 27 * NMAX) {
+      const int n = id / 27, k = id - n * 27;
+      if (n < a.N) atomicAdd(dw + n * 27 + k, acc[o]);
+    }
+  }
+}
+
+static int stem_check(const sy11_conv_desc* d, const char* who) {
+  SY11_REQUIRE(d && dtype_ok(d->dtype), "%s: bad desc", who);
+  SY11_REQUIRE(d->C == 3 && d->KH == 3 && d->KW == 3 && d->DH == 1 && d->DW == 1 && d->groups == 1, "%s: stem kernel is 3x3, Cin=3, dilation 1", who);
+  SY11_REQUIRE(d->N > 0 && d->N <= 64, "%s: N must be <= 64", who);
+  SY11_REQUIRE(d->OH == (d->IH + 2 * d->PH - 3) / d->SH + 1 && d->OW == (d->IW + 2 * d->PW - 3) / d->SW + 1, "%s: OH/OW mismatch", who);
+  SY11_REQUIRE((long)d->B * d->OH * d->OW < (1L << 31), "%s: too many pixels", who);
+  return SY11_OK;
+}
+
+extern "C" int sy11_stem_conv_fwd(const sy11_conv_desc* d, const float* x_nchw, const void* w, const float* bias, void* y,
+                                  float* stat_sum, float* stat_sq, void* stream) {
+  int rc = stem_check(d, "stem_conv_fwd");
+  if (rc) return rc;
+  SY11_REQUIRE(x_nchw && w && y && d->y_ld >= d->N, "stem_conv_fwd: bad argument");
+  StemArgs a{x_nchw, w, y, bias, stat_sum, stat_sq, d->B, d->IH, d->IW, d->OH, d->OW, d->N, d->y_ld, d->SH, d->SW, d->PH, d->PW, d->flags};
+  const long M = (long)d->B * d->OH * d->OW;
+  dim3 grid((unsigned)((M + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->N <= 16) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 16>), grid, block, 0, st, a)); }
+  else if (d->N <= 32) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 32>), grid, block, 0, st, a)); }
+  else { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 64>), grid, block, 0, st, a)); }
+  SY11_LAUNCH_CHECK("stem_conv_fwd");
+  return SY11_OK;
+}
+
+extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw, const void* dy, int32_t dy_ld, float* dw,
+                                    void* stream) {
+  int rc = stem_check(d, "stem_conv_wgrad");
+  if (rc) return rc;
+  SY11_REQUIRE(x_nchw && dy && dw && dy_ld >= d->N, "stem_conv_wgrad: bad argument");
+  StemArgs a{x_nchw, nullptr, (void*)dy, nullptr, nullptr, nullptr, d->B, d->IH, d->IW, d->OH, d->OW, d->N, 0, d->SH, d->SW, d->PH, d->PW, 0};
+  const long M = (long)d->B * d->OH * d->OW;
+  long nblk = (M + 1023) / 1024;
+  if (nblk > 2048) nblk = 2048;
+  const long ppb = ((M + nblk - 1) / nblk + 63) / 64 * 64;
+  nblk = (M + ppb - 1) / ppb;
+  dim3 grid((unsigned)nblk), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->N <= 16) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 16>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
+  else if (d->N <= 32) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 32>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
+  else { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 64>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
+  SY11_LAUNCH_CHECK("stem_conv_wgrad");
+  return SY11_OK;
+}

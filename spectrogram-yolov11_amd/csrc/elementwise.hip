@@ -1,0 +1,545 @@
+// elementwise.hip — HBM-bound NHWC kernels around the convolutions (gfx950): BatchNorm finalize / apply / backward,
+// SiLU, residual add, strided channel-slice copies (concat by pointer), nearest 2x upsample, 5x5 max-pool.
+//
+// Common shape: a tensor view is M pixels x C channels with a pixel stride `ld`.  A thread owns ONE fixed
+// channel vector (VEC = 16 bytes of channels when alignment allows, else 1 element) and walks rows, so the
+// per-channel parameters are loaded once and every global access of a wave is a run of full 16-byte lanes.
+#include "common.h"
+
+template <typename T, int VEC> struct Vec {
+  T v[VEC];
+};
+template <typename T, int VEC>
+__device__ __forceinline__ void vload(const T* p, float* f) {
+  if constexpr (VEC == 1) {
+    f[0] = ElemTraits<T>::to_f(*p);
+  } else {
+    typedef T vt __attribute__((ext_vector_type(VEC)));
+    const vt v = *(const vt*)p;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = ElemTraits<T>::to_f(v[i]);
+  }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void vstore(T* p, const float* f) {
+  if constexpr (VEC == 1) {
+    *p = ElemTraits<T>::from_f(f[0]);
+  } else {
+    typedef T vt __attribute__((ext_vector_type(VEC)));
+    vt v;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = ElemTraits<T>::from_f(f[i]);
+    *(vt*)p = v;
+  }
+}
+
+// rows-per-block geometry shared by the row-walking kernels
+struct RowGeom {
+  int cpv;        // channel vectors per row
+  int rows_pb;    // rows handled concurrently by one block (256 / min(cpv,256))
+  int cblocks;    // blocks along channels (cpv > 256)
+};
+static RowGeom row_geom(int C, int vec) {
+  RowGeom g;
+  g.cpv = C / vec;
+  const int cw = g.cpv < 256 ? g.cpv : 256;
+  g.rows_pb = 256 / cw;
+  g.cblocks = cdiv(g.cpv, 256);
+  return g;
+}
+static bool vec_ok(int esz, int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+  const int vec = 16 / esz;
+  if (C % vec) return false;
+  for (int l : lds) if (l % vec) return false;
+  for (const void* p : ptrs) if (p && ((uintptr_t)p & 15)) return false;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------ BN finalize
+__global__ void bn_finalize_kernel(int C, double count, const float* __restrict__ ssum, const float* __restrict__ ssq,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = (double)ssum[c] / count;
+  double var = (double)ssq[c] / count - mu * mu;
+  if (var < 0) var = 0;
+  const float r = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  rstd[c] = r;
+  const float sc = gamma[c] * r;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mu * sc;
+  if (running_mean) {
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+extern "C" int sy11_bn_finalize(int32_t C, double count, const float* stat_sum, const float* stat_sq, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                float* mean, float* rstd, float* scale, float* shift, void* stream) {
+  SY11_REQUIRE(C > 0 && count > 0, "bn_finalize: bad C/count");
+  SY11_REQUIRE(stat_sum && stat_sq && gamma && beta && mean && rstd && scale && shift, "bn_finalize: null pointer");
+  SY11_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must both be given or both NULL");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, C, count, stat_sum, stat_sq, gamma,
+                     beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
+  SY11_LAUNCH_CHECK("bn_finalize");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ BN apply (+SiLU, +res)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(long M, int C, const T* __restrict__ y, int y_ld, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int silu, const T* __restrict__ res, int res_ld,
+                                                         T* __restrict__ z, int z_ld, int cpv, int rows_pb) {
+  const int cw = cpv < 256 ? cpv : 256;
+  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
+  const int rsub = threadIdx.x / cw;
+  if (cv >= cpv || rsub >= rows_pb) return;
+  const int c = cv * VEC;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { sc[i] = scale ? scale[c + i] : 1.f; sh[i] = shift ? shift[c + i] : 0.f; }
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
+    float v[VEC];
+    vload<T, VEC>(y + m * y_ld + c, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float t = v[i] * sc[i] + sh[i];
+      v[i] = silu ? silu_f(t) : t;
+    }
+    if (res) {
+      float r[VEC];
+      vload<T, VEC>(res + m * res_ld + c, r);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] += r[i];
+    }
+    vstore<T, VEC>(z + m * z_ld + c, v);
+  }
+}
+
+static inline int row_grid(long M, int rows_pb) {
+  long g = (M + rows_pb - 1) / rows_pb;
+  const long cap = 256L * 16;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const float* scale,
+                               const float* shift, int32_t silu, const void* res, int32_t res_ld, void* z, int32_t z_ld,
+                               void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && M > 0 && C > 0 && y && z, "bn_act_fwd: bad argument");
+  SY11_REQUIRE(y_ld >= C && z_ld >= C && (!res || res_ld >= C), "bn_act_fwd: pixel stride < C");
+  const int esz = dtype_size(dtype);
+  const bool v = vec_ok(esz, C, {y_ld, z_ld, res ? res_ld : 16}, {y, z, res});
+  const RowGeom g = row_geom(C, v ? 16 / esz : 1);
+  dim3 grid(row_grid(M, g.rows_pb), g.cblocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (v) hipLaunchKernelGGL((bn_act_fwd_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, scale, shift, silu, (const T*)res, res_ld, (T*)z, z_ld, g.cpv, g.rows_pb);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, scale, shift, silu, (const T*)res, res_ld, (T*)z, z_ld, g.cpv, g.rows_pb);
+  });
+  SY11_LAUNCH_CHECK("bn_act_fwd");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ BN backward
+// pass 1: per-channel sums of g = dz*act'(u), u = y*scale+shift, and of g*xhat, xhat = (y-mean)*rstd
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const T* __restrict__ y, int y_ld, const T* __restrict__ dz, int dz_ld,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift, int silu,
+                                                            float* sum_g, float* sum_gx, int cpv, int rows_pb, long rows_per_block) {
+  __shared__ float red[2][256][VEC > 1 ? VEC : 1];
+  const int cw = cpv < 256 ? cpv : 256;
+  const int cl = threadIdx.x % cw;
+  const int cv = blockIdx.y * 256 + cl;
+  const int rsub = threadIdx.x / cw;
+  const bool active = cv < cpv && rsub < rows_pb;
+  const int c = cv * VEC;
+  float sg[VEC], sgx[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) sg[i] = sgx[i] = 0.f;
+  if (active) {
+    float mu[VEC], rs[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { mu[i] = mean[c + i]; rs[i] = rstd[c + i]; sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
+    const long m0 = (long)blockIdx.x * rows_per_block;
+    const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    for (long m = m0 + rsub; m < m1; m += rows_pb) {
+      float vy[VEC], vg[VEC];
+      vload<T, VEC>(y + m * y_ld + c, vy);
+      vload<T, VEC>(dz + m * dz_ld + c, vg);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float g = vg[i];
+        if (silu) g *= dsilu_f(vy[i] * sc[i] + sh[i]);
+        sg[i] += g;
+        sgx[i] += g * (vy[i] - mu[i]) * rs[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { red[0][threadIdx.x][i] = sg[i]; red[1][threadIdx.x][i] = sgx[i]; }
+  __syncthreads();
+  if (rsub == 0 && cv < cpv) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < rows_pb; ++r) { a += red[0][r * cw + cl][i]; b += red[1][r * cw + cl][i]; }
+      atomicAdd(sum_g + c + i, a);
+      atomicAdd(sum_gx + c + i, b);
+    }
+  }
+}
+
+extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
+                                      int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
+                                      const float* shift, int32_t silu, float* sum_g, float* sum_gx, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && M > 0 && C > 0 && y && dz && mean && rstd && scale && shift && sum_g && sum_gx, "bn_act_bwd_reduce: bad argument");
+  SY11_REQUIRE(y_ld >= C && dz_ld >= C, "bn_act_bwd_reduce: pixel stride < C");
+  const int esz = dtype_size(dtype);
+  const bool v = vec_ok(esz, C, {y_ld, dz_ld}, {y, dz});
+  const RowGeom g = row_geom(C, v ? 16 / esz : 1);
+  long nblk = (M + g.rows_pb * 16L - 1) / (g.rows_pb * 16L);   // >= 16 rows per thread
+  if (nblk > 2048) nblk = 2048;
+  if (nblk < 1) nblk = 1;
+  const long rpb = ((M + nblk - 1) / nblk + g.rows_pb - 1) / g.rows_pb * g.rows_pb;
+  nblk = (M + rpb - 1) / rpb;
+  dim3 grid((unsigned)nblk, g.cblocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, silu, sum_g, sum_gx, g.cpv, g.rows_pb, rpb);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, silu, sum_g, sum_gx, g.cpv, g.rows_pb, rpb);
+  });
+  SY11_LAUNCH_CHECK("bn_act_bwd_reduce");
+  return SY11_OK;
+}
+
+// pass 2: dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); block (0,*) also accumulates dgamma/dbeta
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const T* __restrict__ y, int y_ld, const T* __restrict__ dz, int dz_ld,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ gamma, int silu, const float* __restrict__ sum_g,
+                                                           const float* __restrict__ sum_gx, T* __restrict__ dy, int dy_ld, float* dgamma,
+                                                           float* dbeta, int cpv, int rows_pb) {
+  const int cw = cpv < 256 ? cpv : 256;
+  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
+  const int rsub = threadIdx.x / cw;
+  if (cv >= cpv || rsub >= rows_pb) return;
+  const int c = cv * VEC;
+  const float invM = 1.0f / (float)M;
+  float mu[VEC], rs[VEC], sc[VEC], sh[VEC], k0[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    mu[i] = mean[c + i]; rs[i] = rstd[c + i]; sc[i] = scale[c + i]; sh[i] = shift[c + i];
+    const float gr = gamma[c + i] * rs[i];
+    k0[i] = gr;
+    k1[i] = gr * sum_g[c + i] * invM;
+    k2[i] = gr * sum_gx[c + i] * invM;
+  }
+  if (blockIdx.x == 0 && rsub == 0 && dgamma) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { atomicAdd(dgamma + c + i, sum_gx[c + i]); atomicAdd(dbeta + c + i, sum_g[c + i]); }
+  }
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
+    float vy[VEC], vg[VEC];
+    vload<T, VEC>(y + m * y_ld + c, vy);
+    vload<T, VEC>(dz + m * dz_ld + c, vg);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float g = vg[i];
+      if (silu) g *= dsilu_f(vy[i] * sc[i] + sh[i]);
+      const float xhat = (vy[i] - mu[i]) * rs[i];
+      vg[i] = k0[i] * g - k1[i] - xhat * k2[i];
+    }
+    vstore<T, VEC>(dy + m * dy_ld + c, vg);
+  }
+}
+
+extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
+                                     int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
+                                     const float* shift, const float* gamma, int32_t silu, const float* sum_g,
+                                     const float* sum_gx, void* dy, int32_t dy_ld, float* dgamma, float* dbeta, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && M > 0 && C > 0 && y && dz && dy && mean && rstd && scale && shift && gamma && sum_g && sum_gx, "bn_act_bwd_apply: bad argument");
+  SY11_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_act_bwd_apply: dgamma/dbeta both or neither");
+  SY11_REQUIRE(y_ld >= C && dz_ld >= C && dy_ld >= C, "bn_act_bwd_apply: pixel stride < C");
+  const int esz = dtype_size(dtype);
+  const bool v = vec_ok(esz, C, {y_ld, dz_ld, dy_ld}, {y, dz, dy});
+  const RowGeom g = row_geom(C, v ? 16 / esz : 1);
+  dim3 grid(row_grid(M, g.rows_pb), g.cblocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (v) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb);
+  });
+  SY11_LAUNCH_CHECK("bn_act_bwd_apply");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ strided copy / accumulate
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void copy2d_kernel(long M, int C, const T* __restrict__ src, int src_ld, T* __restrict__ dst, int dst_ld,
+                                                     int accumulate, int cpv, int rows_pb) {
+  const int cw = cpv < 256 ? cpv : 256;
+  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
+  const int rsub = threadIdx.x / cw;
+  if (cv >= cpv || rsub >= rows_pb) return;
+  const int c = cv * VEC;
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
+    float v[VEC];
+    vload<T, VEC>(src + m * src_ld + c, v);
+    if (accumulate) {
+      float o[VEC];
+      vload<T, VEC>(dst + m * dst_ld + c, o);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] += o[i];
+    }
+    vstore<T, VEC>(dst + m * dst_ld + c, v);
+  }
+}
+
+extern "C" int sy11_copy2d(int32_t dtype, int64_t M, int32_t C, const void* src, int32_t src_ld, void* dst, int32_t dst_ld,
+                           int32_t accumulate, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && M > 0 && C > 0 && src && dst, "copy2d: bad argument");
+  SY11_REQUIRE(src_ld >= C && dst_ld >= C, "copy2d: pixel stride < C");
+  const int esz = dtype_size(dtype);
+  const bool v = vec_ok(esz, C, {src_ld, dst_ld}, {src, dst});
+  const RowGeom g = row_geom(C, v ? 16 / esz : 1);
+  dim3 grid(row_grid(M, g.rows_pb), g.cblocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (v) hipLaunchKernelGGL((copy2d_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)src, src_ld, (T*)dst, dst_ld, accumulate, g.cpv, g.rows_pb);
+    else hipLaunchKernelGGL((copy2d_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)src, src_ld, (T*)dst, dst_ld, accumulate, g.cpv, g.rows_pb);
+  });
+  SY11_LAUNCH_CHECK("copy2d");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ nearest 2x upsample
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(int B, int H, int W, int C, const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld,
+                                                             int cpv, int rows_pb) {
+  const int cw = cpv < 256 ? cpv : 256;
+  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
+  const int rsub = threadIdx.x / cw;
+  if (cv >= cpv || rsub >= rows_pb) return;
+  const int c = cv * VEC;
+  const long M = (long)B * H * W;
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
+    const int w = (int)(m % W);
+    const long t = m / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    float v[VEC];
+    vload<T, VEC>(x + m * x_ld + c, v);
+    const long o = ((long)(b * 2 * H + 2 * h) * (2 * W) + 2 * w);
+    vstore<T, VEC>(y + o * y_ld + c, v);
+    vstore<T, VEC>(y + (o + 1) * y_ld + c, v);
+    vstore<T, VEC>(y + (o + 2 * W) * y_ld + c, v);
+    vstore<T, VEC>(y + (o + 2 * W + 1) * y_ld + c, v);
+  }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(int B, int H, int W, int C, const T* __restrict__ dy, int dy_ld, T* __restrict__ dx, int dx_ld,
+                                                             int accumulate, int cpv, int rows_pb) {
+  const int cw = cpv < 256 ? cpv : 256;
+  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
+  const int rsub = threadIdx.x / cw;
+  if (cv >= cpv || rsub >= rows_pb) return;
+  const int c = cv * VEC;
+  const long M = (long)B * H * W;
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
+    const int w = (int)(m % W);
+    const long t = m / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    const long o = ((long)(b * 2 * H + 2 * h) * (2 * W) + 2 * w);
+    float a[VEC], q[VEC];
+    vload<T, VEC>(dy + o * dy_ld + c, a);
+    vload<T, VEC>(dy + (o + 1) * dy_ld + c, q);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a[i] += q[i];
+    vload<T, VEC>(dy + (o + 2 * W) * dy_ld + c, q);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a[i] += q[i];
+    vload<T, VEC>(dy + (o + 2 * W + 1) * dy_ld + c, q);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a[i] += q[i];
+    if (accumulate) {
+      vload<T, VEC>(dx + m * dx_ld + c, q);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) a[i] += q[i];
+    }
+    vstore<T, VEC>(dx + m * dx_ld + c, a);
+  }
+}
+
+extern "C" int sy11_upsample2x_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, int32_t x_ld,
+                                   void* y, int32_t y_ld, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && x && y && x_ld >= C && y_ld >= C, "upsample2x_fwd: bad argument");
+  const int esz = dtype_size(dtype);
+  const bool v = vec_ok(esz, C, {x_ld, y_ld}, {x, y});
+  const RowGeom g = row_geom(C, v ? 16 / esz : 1);
+  dim3 grid(row_grid((long)B * H * W, g.rows_pb), g.cblocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (v) hipLaunchKernelGGL((upsample2x_fwd_kernel<T, VE>), grid, block, 0, st, B, H, W, C, (const T*)x, x_ld, (T*)y, y_ld, g.cpv, g.rows_pb);
+    else hipLaunchKernelGGL((upsample2x_fwd_kernel<T, 1>), grid, block, 0, st, B, H, W, C, (const T*)x, x_ld, (T*)y, y_ld, g.cpv, g.rows_pb);
+  });
+  SY11_LAUNCH_CHECK("upsample2x_fwd");
+  return SY11_OK;
+}
+extern "C" int sy11_upsample2x_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
+                                   void* dx, int32_t dx_ld, int32_t accumulate, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && dy && dx && dy_ld >= C && dx_ld >= C, "upsample2x_bwd: bad argument");
+  const int esz = dtype_size(dtype);
+  const bool v = vec_ok(esz, C, {dy_ld, dx_ld}, {dy, dx});
+  const RowGeom g = row_geom(C, v ? 16 / esz : 1);
+  dim3 grid(row_grid((long)B * H * W, g.rows_pb), g.cblocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (v) hipLaunchKernelGGL((upsample2x_bwd_kernel<T, VE>), grid, block, 0, st, B, H, W, C, (const T*)dy, dy_ld, (T*)dx, dx_ld, accumulate, g.cpv, g.rows_pb);
+    else hipLaunchKernelGGL((upsample2x_bwd_kernel<T, 1>), grid, block, 0, st, B, H, W, C, (const T*)dy, dy_ld, (T*)dx, dx_ld, accumulate, g.cpv, g.rows_pb);
+  });
+  SY11_LAUNCH_CHECK("upsample2x_bwd");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ 5x5 stride-1 max pool
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool5_fwd_kernel(int B, int H, int W, int C, const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld,
+                                                           uint8_t* __restrict__ idx, int cpv, int rows_pb) {
+  const int cw = cpv < 256 ? cpv : 256;
+  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
+  const int rsub = threadIdx.x / cw;
+  if (cv >= cpv || rsub >= rows_pb) return;
+  const int c = cv * VEC;
+  const long M = (long)B * H * W;
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
+    const int w = (int)(m % W);
+    const long t = m / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    float best[VEC];
+    int bi[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; bi[i] = 12; }
+    bool first = true;
+    for (int wy = 0; wy < 5; ++wy) {
+      const int iy = h + wy - 2;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int wx = 0; wx < 5; ++wx) {
+        const int ix = w + wx - 2;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float v[VEC];
+        vload<T, VEC>(x + ((long)(b * H + iy) * W + ix) * x_ld + c, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+          if (first || v[i] > best[i]) { best[i] = v[i]; bi[i] = wy * 5 + wx; }   // strict >: first maximum wins
+        first = false;
+      }
+    }
+    vstore<T, VEC>(y + m * y_ld + c, best);
+    if (idx) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) idx[m * C + c + i] = (uint8_t)bi[i];
+    }
+  }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(int B, int H, int W, int C, const T* __restrict__ dy, int dy_ld,
+                                                           const uint8_t* __restrict__ idx, T* __restrict__ dx, int dx_ld, int accumulate,
+                                                           int cpv, int rows_pb) {
+  const int cw = cpv < 256 ? cpv : 256;
+  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
+  const int rsub = threadIdx.x / cw;
+  if (cv >= cpv || rsub >= rows_pb) return;
+  const int c = cv * VEC;
+  const long M = (long)B * H * W;
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
+    const int w = (int)(m % W);
+    const long t = m / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    // every window q = p + (oy, ox) that contains p; p sits at window position (2-oy, 2-ox) of q
+    for (int oy = -2; oy <= 2; ++oy) {
+      const int qy = h + oy;
+      if ((unsigned)qy >= (unsigned)H) continue;
+      for (int ox = -2; ox <= 2; ++ox) {
+        const int qx = w + ox;
+        if ((unsigned)qx >= (unsigned)W) continue;
+        const long q = (long)(b * H + qy) * W + qx;
+        const int pos = (2 - oy) * 5 + (2 - ox);
+        float g[VEC];
+        vload<T, VEC>(dy + q * dy_ld + c, g);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+          if (idx[q * C + c + i] == pos) acc[i] += g[i];
+      }
+    }
+    if (accumulate) {
+      float o[VEC];
+      vload<T, VEC>(dx + m * dx_ld + c, o);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += o[i];
+    }
+    vstore<T, VEC>(dx + m * dx_ld + c, acc);
+  }
+}
+
+extern "C" int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, int32_t x_ld,
+                                 void* y, int32_t y_ld, uint8_t* idx, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && x && y && x_ld >= C && y_ld >= C, "maxpool5_fwd: bad argument");
+  const int esz = dtype_size(dtype);
+  const bool v = vec_ok(esz, C, {x_ld, y_ld}, {x, y});
+  const RowGeom g = row_geom(C, v ? 16 / esz : 1);
+  dim3 grid(row_grid((long)B * H * W, g.rows_pb), g.cblocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (v) hipLaunchKernelGGL((maxpool5_fwd_kernel<T, VE>), grid, block, 0, st, B, H, W, C, (const T*)x, x_ld, (T*)y, y_ld, idx, g.cpv, g.rows_pb);
+    else hipLaunchKernelGGL((maxpool5_fwd_kernel<T, 1>), grid, block, 0, st, B, H, W, C, (const T*)x, x_ld, (T*)y, y_ld, idx, g.cpv, g.rows_pb);
+  });
+  SY11_LAUNCH_CHECK("maxpool5_fwd");
+  return SY11_OK;
+}
+extern "C" int sy11_maxpool5_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
+                                 const uint8_t* idx, void* dx, int32_t dx_ld, int32_t accumulate, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && dy && dx && idx && dy_ld >= C && dx_ld >= C, "maxpool5_bwd: bad argument");
+  const int esz = dtype_size(dtype);
+  const bool v = vec_ok(esz, C, {dy_ld, dx_ld}, {dy, dx});
+  const RowGeom g = row_geom(C, v ? 16 / esz : 1);
+  dim3 grid(row_grid((long)B * H * W, g.rows_pb), g.cblocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (v) hipLaunchKernelGGL((maxpool5_bwd_kernel<T, VE>), grid, block, 0, st, B, H, W, C, (const T*)dy, dy_ld, idx, (T*)dx, dx_ld, accumulate, g.cpv, g.rows_pb);
+    else hipLaunchKernelGGL((maxpool5_bwd_kernel<T, 1>), grid, block, 0, st, B, H, W, C, (const T*)dy, dy_ld, idx, (T*)dx, dx_ld, accumulate, g.cpv, g.rows_pb);
+  });
+  SY11_LAUNCH_CHECK("maxpool5_bwd");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ dtype cast
+template <typename S, typename D>
+__global__ void cast_kernel(long n, const S* __restrict__ s, D* __restrict__ d) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    d[i] = ElemTraits<D>::from_f(ElemTraits<S>::to_f(s[i]));
+}
+extern "C" int sy11_cast(int32_t src_dtype, int32_t dst_dtype, int64_t n, const void* src, void* dst, void* stream) {
+  SY11_REQUIRE(dtype_ok(src_dtype) && dtype_ok(dst_dtype) && n > 0 && src && dst, "cast: bad argument");
+  long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(src_dtype, S, SY11_DISPATCH_DTYPE(dst_dtype, D, hipLaunchKernelGGL((cast_kernel<S, D>), dim3((unsigned)g), dim3(256), 0, st, (long)n, (const S*)src, (D*)dst)));
+  SY11_LAUNCH_CHECK("cast");
+  return SY11_OK;
+}

@@ -1,0 +1,417 @@
+// igemm.hip — NHWC implicit-GEMM convolution on MFMA for gfx950 (forward and data-gradient).
+//
+// GEMM view:  D[m][n] = sum_k A[m][k] * Bw[n][k]
+//   m = output pixel of a (B, OH, OW) grid, n = output channel, k = (tap t, channel c).
+//   A is never materialised: row m / column k is gathered from the NHWC input at
+//   (b, oy*sy + tap_dy[t], ox*sx + tap_dx[t], c), zero outside the image (padding) — im2col on the fly.
+//   Bw row n is the filter [n][tap_w[t]][c] (K-contiguous), so both operands are "K-major".
+//
+// Tiling (one 256-thread workgroup = 4 wave64):  BM=128 pixels x BN in {128,64,32} channels x 128 BYTES of K
+// per stage (32 f32 / 64 f16 elements), two LDS stages, register-staged global->LDS copies issued one stage
+// ahead (cdna guide T14), 16-byte ds_read_b128 fragment reads from an XOR-swizzled image
+// (phys_chunk = chunk ^ ((row>>1)&7): conflict-free for the four 16-lane groups of ds_read_b128 on 128-B rows).
+// MFMA: v_mfma_f32_32x32x2_f32 (exact f32, 4 per 16-byte K group) or v_mfma_f32_32x32x16_{f16,bf16}.
+// For f32 the k order inside a 16-byte group is permuted identically for A and B (lane half h owns chunk 2g+h),
+// which leaves the dot product unchanged.
+//
+// The same kernel computes the data gradient: input := dy, filter := tap-transposed weights, taps := the
+// (P - r*D)/S offsets of one output-parity class, output written with a pixel stride (oy*oy_mul+oy_add).
+#include "common.h"
+
+struct IgemmArgs {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* bias;
+  float* stat_sum;
+  float* stat_sq;
+  int M, N, K, C, T;
+  int wK;                 // elements between consecutive filter rows (full T*C of the stored filter)
+  int x_ld, y_ld;
+  int IH, IW, OH, OW;
+  int sy, sx;
+  int OHF, OWF, oy_mul, oy_add, ox_mul, ox_add;
+  int dense_out;          // 1: output offset is m*y_ld (no decode)
+  int tiles_n;
+  unsigned flags;
+  signed char tap_dy[64];
+  signed char tap_dx[64];
+  signed char tap_w[64];
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<_Float16> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<__bf16> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+  constexpr int BM = 128;
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int BK = 8 * EPC;               // elements per 128-byte LDS row
+  constexpr int MI = BM / WM / 32;
+  constexpr int NI = BN / WN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 192];
+  signed char* s_taps = (signed char*)(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of tiles
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+  const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+
+  if (tid < 64) {
+    s_taps[tid] = a.tap_dy[tid];
+    s_taps[64 + tid] = a.tap_dx[tid];
+    s_taps[128 + tid] = a.tap_w[tid];
+  }
+
+  // ---- staging roles: 8 consecutive lanes cover one 128-byte row; rows ld_row + 32*i
+  const int ld_chunk = tid & 7, ld_row = tid >> 3;
+  int a_pix[BM / 32], a_iy[BM / 32], a_ix[BM / 32];
+  const int ohw = a.OH * a.OW;
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i) {
+    const int m = bm0 + ld_row + 32 * i;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / ohw, r = mm - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
+    a_pix[i] = b * a.IH * a.IW;
+    a_iy[i] = ok ? oy * a.sy : -(1 << 20);
+    a_ix[i] = ox * a.sx;
+  }
+  int kt = (ld_chunk * EPC) / a.C;             // tap of this thread's chunk in the current stage
+  int kc = (ld_chunk * EPC) - kt * a.C;        // channel within the tap
+  const T* __restrict__ xg = (const T*)a.x;
+  const T* __restrict__ wg = (const T*)a.w;
+
+  uint4 ra[BM / 32], rb[BN / 32];
+  __syncthreads();  // taps visible
+
+  auto load_stage = [&]() {
+    const bool kvalid = kt < a.T;
+    const int tt = kvalid ? kt : 0;
+    const int dy = s_taps[tt], dx = s_taps[64 + tt], tw = s_taps[128 + tt];
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+      const bool ok = kvalid && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *(const uint4*)(xg + (long)(a_pix[i] + iy * a.IW + ix) * a.x_ld + kc);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int n = bn0 + ld_row + 32 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (kvalid && n < a.N) v = *(const uint4*)(wg + (long)n * a.wK + tw * a.C + kc);
+      rb[i] = v;
+    }
+    kc += BK;
+    while (kc >= a.C) { kc -= a.C; ++kt; }
+  };
+  auto store_stage = [&](int buf) {
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      const int r = ld_row + 32 * i;
+      *(uint4*)(sa + r * 128 + ((ld_chunk ^ ((r >> 1) & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int r = ld_row + 32 * i;
+      *(uint4*)(sb + r * 128 + ((ld_chunk ^ ((r >> 1) & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 31, fh = lane >> 5;
+  const int nstage = (a.K + BK - 1) / BK;
+
+  load_stage();
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const bool more = s + 1 < nstage;
+    if (more) load_stage();
+    const unsigned char* sa = smem + (s & 1) * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint4 fa[MI], fb[NI];
+      const int ch = 2 * g + fh;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * (BM / WM) + i * 32 + frow;
+        fa[i] = *(const uint4*)(sa + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int r = wn * (BN / WN) + j * 32 + frow;
+        fb[j] = *(const uint4*)(sb + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) store_stage((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const bool do_stats = a.stat_sum != nullptr;
+  const bool silu = a.flags & SY11_EPI_SILU, accum = a.flags & SY11_EPI_ACCUM, out32 = a.flags & SY11_EPI_OUT_F32;
+  float ssum[NI], ssq[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) ssum[j] = ssq[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = bm0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+      if (m >= a.M) continue;
+      long obase;
+      if (a.dense_out) {
+        obase = (long)m * a.y_ld;
+      } else {
+        const int b = m / ohw, r = m - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
+        obase = ((long)(b * a.OHF + oy * a.oy_mul + a.oy_add) * a.OWF + ox * a.ox_mul + a.ox_add) * a.y_ld;
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = bn0 + wn * (BN / WN) + j * 32 + frow;
+        if (n >= a.N) continue;
+        float v = acc[i][j][e];
+        ssum[j] += v;
+        ssq[j] += v * v;
+        if (a.bias) v += a.bias[n];
+        if (silu) v = silu_f(v);
+        if (out32) {
+          float* yp = (float*)a.y + obase + n;
+          if (accum) v += *yp;
+          *yp = v;
+        } else {
+          T* yp = (T*)a.y + obase + n;
+          if (accum) v += ElemTraits<T>::to_f(*yp);
+          *yp = ElemTraits<T>::from_f(v);
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    float* red = (float*)smem;  // [2][BN]; main-loop LDS is dead after the final barrier
+    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float s1 = ssum[j] + __shfl_xor(ssum[j], 32);
+      float s2 = ssq[j] + __shfl_xor(ssq[j], 32);
+      if (fh == 0) {
+        const int col = wn * (BN / WN) + j * 32 + frow;
+        atomicAdd(&red[col], s1);
+        atomicAdd(&red[BN + col], s2);
+      }
+    }
+    __syncthreads();
+    if (tid < BN && bn0 + tid < a.N) {
+      atomicAdd(a.stat_sum + bn0 + tid, red[tid]);
+      atomicAdd(a.stat_sq + bn0 + tid, red[BN + tid]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <typename T>
+static int launch_igemm(IgemmArgs& a, hipStream_t st) {
+  const int tiles_m = cdiv(a.M, 128);
+  int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  a.tiles_n = cdiv(a.N, bn);
+  const long nwg = (long)tiles_m * a.tiles_n;
+  if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
+  dim3 grid((unsigned)nwg), block(256);
+  if (bn == 128) hipLaunchKernelGGL((igemm_kernel<T, 128, 2, 2>), grid, block, 0, st, a);
+  else if (bn == 64) hipLaunchKernelGGL((igemm_kernel<T, 64, 4, 1>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((igemm_kernel<T, 32, 4, 1>), grid, block, 0, st, a);
+  SY11_LAUNCH_CHECK("igemm");
+  return SY11_OK;
+}
+
+static int validate_conv(const sy11_conv_desc* d, const char* who) {
+  SY11_REQUIRE(d != nullptr, "%s: null desc", who);
+  SY11_REQUIRE(dtype_ok(d->dtype), "%s: bad dtype %d", who, d->dtype);
+  SY11_REQUIRE(d->B > 0 && d->IH > 0 && d->IW > 0 && d->C > 0 && d->N > 0, "%s: non-positive dims", who);
+  SY11_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 64, "%s: kernel %dx%d unsupported (<=64 taps)", who, d->KH, d->KW);
+  SY11_REQUIRE(d->SH > 0 && d->SW > 0 && d->DH > 0 && d->DW > 0 && d->PH >= 0 && d->PW >= 0, "%s: bad stride/dilation/pad", who);
+  const int oh = (d->IH + 2 * d->PH - d->DH * (d->KH - 1) - 1) / d->SH + 1;
+  const int ow = (d->IW + 2 * d->PW - d->DW * (d->KW - 1) - 1) / d->SW + 1;
+  SY11_REQUIRE(oh == d->OH && ow == d->OW, "%s: OH/OW (%d,%d) do not match conv arithmetic (%d,%d)", who, d->OH, d->OW, oh, ow);
+  SY11_REQUIRE(d->x_ld >= d->C && d->y_ld >= d->N, "%s: pixel stride smaller than channel count", who);
+  SY11_REQUIRE((long)d->B * d->IH * d->IW < (1L << 31) && (long)d->B * d->OH * d->OW < (1L << 31), "%s: pixel count overflows int32", who);
+  SY11_REQUIRE(d->PH * 1 < 120 && d->DH * (d->KH - 1) < 120 && d->PW < 120 && d->DW * (d->KW - 1) < 120, "%s: tap offset exceeds int8", who);
+  return SY11_OK;
+}
+
+static int check_align(const void* p, int ld, int c, int esz, const char* who, const char* what) {
+  SY11_REQUIRE(p != nullptr, "%s: null %s", who, what);
+  SY11_REQUIRE(((uintptr_t)p & 15) == 0, "%s: %s pointer not 16-byte aligned", who, what);
+  SY11_REQUIRE(((long)ld * esz) % 16 == 0, "%s: %s pixel stride %d not a multiple of 16 bytes", who, what, ld);
+  SY11_REQUIRE(((long)c * esz) % 16 == 0, "%s: %s channel count %d not a multiple of 16 bytes", who, what, c);
+  return SY11_OK;
+}
+
+int sy11_dwconv_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                         float* stat_sum, float* stat_sq, hipStream_t st);
+int sy11_dwconv_dgrad_impl(const sy11_conv_desc* d, const void* dy, int dy_ld, const void* w, void* dx, hipStream_t st);
+
+extern "C" int sy11_conv2d_fwd(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                               float* stat_sum, float* stat_sq, void* stream) {
+  int rc = validate_conv(d, "conv2d_fwd");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->groups != 1) {
+    SY11_REQUIRE(d->groups == d->C && d->C == d->N, "conv2d_fwd: only groups==1 or depthwise (groups==C==N) supported");
+    return sy11_dwconv_fwd_impl(d, x, w, bias, y, stat_sum, stat_sq, st);
+  }
+  const int esz = dtype_size(d->dtype);
+  if ((rc = check_align(x, d->x_ld, d->C, esz, "conv2d_fwd", "x"))) return rc;
+  SY11_REQUIRE(w && y, "conv2d_fwd: null w/y");
+  SY11_REQUIRE(((uintptr_t)w & 15) == 0, "conv2d_fwd: w not 16-byte aligned");
+  SY11_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv2d_fwd: stat_sum and stat_sq must both be given or both NULL");
+  IgemmArgs a{};
+  a.x = x; a.w = w; a.y = y; a.bias = bias; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  a.T = d->KH * d->KW; a.C = d->C; a.K = a.T * a.C; a.wK = a.K;
+  a.M = d->B * d->OH * d->OW; a.N = d->N;
+  a.x_ld = d->x_ld; a.y_ld = d->y_ld;
+  a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW;
+  a.sy = d->SH; a.sx = d->SW;
+  a.OHF = d->OH; a.OWF = d->OW; a.oy_mul = a.ox_mul = 1; a.oy_add = a.ox_add = 0; a.dense_out = 1;
+  a.flags = d->flags;
+  for (int r = 0; r < d->KH; ++r)
+    for (int s = 0; s < d->KW; ++s) {
+      const int t = r * d->KW + s;
+      a.tap_dy[t] = (signed char)(r * d->DH - d->PH);
+      a.tap_dx[t] = (signed char)(s * d->DW - d->PW);
+      a.tap_w[t] = (signed char)t;
+    }
+  SY11_DISPATCH_DTYPE(d->dtype, T, return launch_igemm<T>(a, st));
+}
+
+extern "C" int sy11_conv2d_dgrad(const sy11_conv_desc* d, const void* dy, int32_t dy_ld, const void* wt, void* dx,
+                                 void* stream) {
+  int rc = validate_conv(d, "conv2d_dgrad");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->groups != 1) {
+    SY11_REQUIRE(d->groups == d->C && d->C == d->N, "conv2d_dgrad: only groups==1 or depthwise supported");
+    return sy11_dwconv_dgrad_impl(d, dy, dy_ld, wt, dx, st);
+  }
+  const int esz = dtype_size(d->dtype);
+  SY11_REQUIRE(dy_ld >= d->N, "conv2d_dgrad: dy_ld < N");
+  if ((rc = check_align(dy, dy_ld, d->N, esz, "conv2d_dgrad", "dy"))) return rc;
+  SY11_REQUIRE(wt && dx, "conv2d_dgrad: null wt/dx");
+  SY11_REQUIRE(((uintptr_t)wt & 15) == 0, "conv2d_dgrad: wt not 16-byte aligned");
+  SY11_REQUIRE(!(d->flags & (SY11_EPI_SILU | SY11_EPI_OUT_F32)), "conv2d_dgrad: only SY11_EPI_ACCUM is meaningful");
+  // one launch per output-parity class (ph, pw): pixels i = SH*i' + ph use only taps with (ph + PH - r*DH) % SH == 0
+  for (int ph = 0; ph < d->SH; ++ph)
+    for (int pw = 0; pw < d->SW; ++pw) {
+      if (ph >= d->IH || pw >= d->IW) continue;
+      IgemmArgs a{};
+      a.x = dy; a.w = wt; a.y = dx; a.bias = nullptr;
+      a.C = d->N; a.wK = d->KH * d->KW * d->N;
+      a.N = d->C;
+      a.x_ld = dy_ld; a.y_ld = d->x_ld;
+      a.IH = d->OH; a.IW = d->OW;
+      a.OH = (d->IH - ph + d->SH - 1) / d->SH; a.OW = (d->IW - pw + d->SW - 1) / d->SW;
+      a.M = d->B * a.OH * a.OW;
+      a.sy = 1; a.sx = 1;
+      a.OHF = d->IH; a.OWF = d->IW; a.oy_mul = d->SH; a.oy_add = ph; a.ox_mul = d->SW; a.ox_add = pw;
+      a.dense_out = (d->SH == 1 && d->SW == 1);
+      a.flags = d->flags & SY11_EPI_ACCUM;
+      int t = 0;
+      for (int r = 0; r < d->KH; ++r) {
+        const int ny = ph + d->PH - r * d->DH;
+        if (((ny % d->SH) + d->SH) % d->SH) continue;
+        for (int s = 0; s < d->KW; ++s) {
+          const int nx = pw + d->PW - s * d->DW;
+          if (((nx % d->SW) + d->SW) % d->SW) continue;
+          const int oy_off = (ny >= 0 ? ny / d->SH : -((-ny) / d->SH));   // exact: ny divisible by SH
+          const int ox_off = (nx >= 0 ? nx / d->SW : -((-nx) / d->SW));
+          a.tap_dy[t] = (signed char)oy_off;
+          a.tap_dx[t] = (signed char)ox_off;
+          a.tap_w[t] = (signed char)(r * d->KW + s);
+          ++t;
+        }
+      }
+      a.T = t;
+      a.K = t * a.C;
+      if (t == 0) {
+        // no tap reaches this parity class: gradient is zero there
+        if (!(d->flags & SY11_EPI_ACCUM)) SY11_FAIL(SY11_EUNSUPPORTED, "conv2d_dgrad: stride leaves untouched input pixels; zero dx and pass SY11_EPI_ACCUM");
+        continue;
+      }
+      SY11_DISPATCH_DTYPE(d->dtype, T, rc = launch_igemm<T>(a, st));
+      if (rc) return rc;
+    }
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight transpose
+template <typename T>
+__global__ void weight_transpose_kernel(int N, int T_, int C, const T* __restrict__ w, T* __restrict__ wt) {
+  // wt[c][t][n] = w[n][t][c]; 32x32 LDS tile transpose over (n, c) for each tap
+  __shared__ T tile[32][33];
+  const int t = blockIdx.z;
+  const int n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int n = n0 + j, c = c0 + tx;
+    tile[j][tx] = (n < N && c < C) ? w[((long)n * T_ + t) * C + c] : (T)0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, n = n0 + tx;
+    if (c < C && n < N) wt[((long)c * T_ + t) * N + n] = tile[tx][j];
+  }
+}
+
+extern "C" int sy11_weight_transpose(int32_t dtype, int32_t N, int32_t T_, int32_t C, const void* w, void* wt, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype), "weight_transpose: bad dtype");
+  SY11_REQUIRE(N > 0 && T_ > 0 && C > 0 && T_ <= 65535, "weight_transpose: bad dims");
+  SY11_REQUIRE(w && wt, "weight_transpose: null pointer");
+  dim3 grid(cdiv(C, 32), cdiv(N, 32), T_), block(256);
+  SY11_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((weight_transpose_kernel<T>), grid, block, 0, (hipStream_t)stream, N, T_, C, (const T*)w, (T*)wt));
+  SY11_LAUNCH_CHECK("weight_transpose");
+  return SY11_OK;
+}

@@ -1,0 +1,199 @@
+// wgrad.hip — filter gradient of the NHWC convolution on MFMA (gfx950).
+//
+// dW[n][t][c] += sum_m dy[m][n] * x[pix(m,t)][c]        (m = output pixel, t = tap)
+// GEMM view: rows = n (output channel), cols = kk = (t, c), reduction over the B*OH*OW pixels.
+// Both operands are "pixel-major" in HBM (NHWC), i.e. the reduction index is the SLOW index of both tiles, so
+// the tiles are staged as [pixel][n] and [pixel][kk] f32 images in LDS and the one-float-per-lane fragments of
+// v_mfma_f32_32x32x2_f32 (A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]) are read with conflict-free
+// ds_read_b32 (32 consecutive floats per lane half).  f16/bf16 inputs are widened to f32 on the way into LDS
+// (round 1: exact products, f32 MFMA rate; the 16-bit MFMA path with ds_read_b64_tr_b16 is the next step).
+// The pixel range is split over gridDim.y; partial tiles are added to dW with f32 atomics whose 32-lane groups
+// cover 128 contiguous bytes.
+#include "common.h"
+
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  float* dw;
+  int M, N, K, C, T;
+  int x_ld, dy_ld;
+  int IH, IW, OH, OW, sy, sx;
+  int tiles_k;
+  int pix_per_split;     // multiple of BP
+  signed char tap_dy[64];
+  signed char tap_dx[64];
+};
+
+template <typename T>
+__device__ __forceinline__ void load_chunk_f32(const T* p, float* out);
+template <>
+__device__ __forceinline__ void load_chunk_f32<float>(const float* p, float* out) {
+  const f32x4 v = *(const f32x4*)p;
+  out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
+template <>
+__device__ __forceinline__ void load_chunk_f32<_Float16>(const _Float16* p, float* out) {
+  const f16x8 v = *(const f16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
+template <>
+__device__ __forceinline__ void load_chunk_f32<__bf16>(const __bf16* p, float* out) {
+  const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
+
+// TILE = 128 (2x2 waves, 2x2 MFMA tiles each) or 64 (2x2 waves, 1 MFMA tile each)
+template <typename T, int TILE>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+  constexpr int BP = 32;                          // pixels per stage
+  constexpr int EPC = 16 / (int)sizeof(T);        // elements per 16-byte global chunk
+  constexpr int CPR = TILE / EPC;                 // chunks per tile row
+  constexpr int RPP = 256 / CPR;                  // pixel rows covered per pass
+  constexpr int NPASS = BP / RPP;
+  constexpr int FI = TILE / 64;                   // MFMA tiles per wave per dim
+  constexpr int LDW = TILE + 0;                   // f32 words per LDS row
+  static_assert(NPASS >= 1, "tile too wide");
+  __shared__ __attribute__((aligned(16))) float smem[2][2][BP][LDW];   // [stage][dy|x][pixel][col]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_k = blockIdx.x % a.tiles_k, tile_n = blockIdx.x / a.tiles_k;
+  const int n0 = tile_n * TILE, k0 = tile_k * TILE;
+  const int m_begin = blockIdx.y * a.pix_per_split;
+  const int m_end = min(a.M, m_begin + a.pix_per_split);
+  if (m_begin >= m_end) return;
+
+  const int chunk = tid % CPR, prow = tid / CPR;
+  // dy chunk: channels n0 + chunk*EPC ..; x chunk: kk = k0 + chunk*EPC -> (t, c) fixed for the whole pixel loop
+  const int ncol = n0 + chunk * EPC;
+  const bool n_ok = ncol < a.N;                     // N % EPC == 0 is required by the host
+  const int kk = k0 + chunk * EPC;
+  const bool k_ok = kk < a.K;
+  const int kt = k_ok ? kk / a.C : 0, kc = k_ok ? kk - kt * a.C : 0;
+  const int tdy = a.tap_dy[kt], tdx = a.tap_dx[kt];
+  const int ohw = a.OH * a.OW;
+  const T* __restrict__ xg = (const T*)a.x;
+  const T* __restrict__ dyg = (const T*)a.dy;
+
+  float rdy[NPASS][EPC], rx[NPASS][EPC];
+  auto load_stage = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int m = m0 + prow + p * RPP;
+      const bool ok = m < m_end;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) rdy[p][e] = rx[p][e] = 0.f;
+      if (ok && n_ok) load_chunk_f32<T>(dyg + (long)m * a.dy_ld + ncol, rdy[p]);
+      if (ok && k_ok) {
+        const int b = m / ohw, r = m - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
+        const int iy = oy * a.sy + tdy, ix = ox * a.sx + tdx;
+        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
+          load_chunk_f32<T>(xg + (long)((b * a.IH + iy) * a.IW + ix) * a.x_ld + kc, rx[p]);
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int r = prow + p * RPP;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        *(f32x4*)&smem[buf][0][r][chunk * EPC + e] = f32x4{rdy[p][e], rdy[p][e + 1], rdy[p][e + 2], rdy[p][e + 3]};
+        *(f32x4*)&smem[buf][1][r][chunk * EPC + e] = f32x4{rx[p][e], rx[p][e + 1], rx[p][e + 2], rx[p][e + 3]};
+      }
+    }
+  };
+
+  f32x16 acc[FI][FI];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fcol = lane & 31, fh = lane >> 5;
+
+  const int nstage = (m_end - m_begin + BP - 1) / BP;
+  load_stage(m_begin);
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const bool more = s + 1 < nstage;
+    if (more) load_stage(m_begin + (s + 1) * BP);
+    const int buf = s & 1;
+#pragma unroll
+    for (int pp = 0; pp < BP / 2; ++pp) {
+      float fa[FI], fb[FI];
+#pragma unroll
+      for (int i = 0; i < FI; ++i) fa[i] = smem[buf][0][2 * pp + fh][wr * (TILE / 2) + i * 32 + fcol];
+#pragma unroll
+      for (int j = 0; j < FI; ++j) fb[j] = smem[buf][1][2 * pp + fh][wc * (TILE / 2) + j * 32 + fcol];
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+  // D map: col = lane&31 (kk), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (n)
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wr * (TILE / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int k = k0 + wc * (TILE / 2) + j * 32 + fcol;
+        if (n < a.N && k < a.K) atomicAdd(a.dw + (long)n * a.K + k, acc[i][j][e]);
+      }
+}
+
+extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, const void* dy, int dy_ld, float* dw, hipStream_t st);
+extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const void* dy, int32_t dy_ld, float* dw,
+                                 void* stream) {
+  SY11_REQUIRE(d && x && dy && dw, "conv2d_wgrad: null argument");
+  SY11_REQUIRE(dtype_ok(d->dtype), "conv2d_wgrad: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->groups != 1) {
+    SY11_REQUIRE(d->groups == d->C && d->C == d->N, "conv2d_wgrad: only groups==1 or depthwise supported");
+    return sy11_conv2d_wgrad_dw(d, x, dy, dy_ld, dw, st);
+  }
+  const int esz = dtype_size(d->dtype), epc = 16 / esz;
+  SY11_REQUIRE(d->KH * d->KW <= 64 && d->KH > 0 && d->KW > 0, "conv2d_wgrad: <=64 taps");
+  SY11_REQUIRE(d->C % epc == 0 && d->N % epc == 0, "conv2d_wgrad: C and N must be multiples of %d", epc);
+  SY11_REQUIRE(d->x_ld % epc == 0 && dy_ld % epc == 0 && d->x_ld >= d->C && dy_ld >= d->N, "conv2d_wgrad: bad pixel strides");
+  SY11_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && ((uintptr_t)dw & 3) == 0, "conv2d_wgrad: misaligned pointer");
+  SY11_REQUIRE((long)d->B * d->IH * d->IW < (1L << 31) && (long)d->B * d->OH * d->OW < (1L << 31), "conv2d_wgrad: pixel count overflows int32");
+  WgradArgs a{};
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.T = d->KH * d->KW; a.C = d->C; a.K = a.T * a.C; a.N = d->N;
+  a.M = d->B * d->OH * d->OW;
+  a.x_ld = d->x_ld; a.dy_ld = dy_ld;
+  a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.sy = d->SH; a.sx = d->SW;
+  for (int r = 0; r < d->KH; ++r)
+    for (int s = 0; s < d->KW; ++s) {
+      a.tap_dy[r * d->KW + s] = (signed char)(r * d->DH - d->PH);
+      a.tap_dx[r * d->KW + s] = (signed char)(s * d->DW - d->PW);
+    }
+  const int tile = (a.N > 64 && a.K > 64) ? 128 : 64;
+  a.tiles_k = cdiv(a.K, tile);
+  const int tiles = a.tiles_k * cdiv(a.N, tile);
+  // enough pixel splits to put ~4 workgroups on each of the 256 CUs, but >= 8 stages (256 pixels) per split
+  int splits = cdiv(1024, tiles);
+  const int max_splits = cdiv(a.M, 256);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.pix_per_split = cdiv(cdiv(a.M, splits), 32) * 32;
+  splits = cdiv(a.M, a.pix_per_split);
+  dim3 grid(tiles, splits), block(256);
+  if (tile == 128) {
+    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((wgrad_kernel<T, 128>), grid, block, 0, st, a));
+  } else {
+    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((wgrad_kernel<T, 64>), grid, block, 0, st, a));
+  }
+  SY11_LAUNCH_CHECK("conv2d_wgrad");
+  return SY11_OK;
+}

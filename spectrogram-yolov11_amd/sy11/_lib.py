@@ -1,0 +1,94 @@
+"""ctypes binding of libsy11.so (the C-ABI declared in include/sy11.h).
+
+The product path has NO fallback: if the shared library is missing, or a call returns an error code, this
+module raises.  Nothing here imports the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("SY11_LIB", _HERE / "libsy11.so"))
+
+F32, F16, BF16 = 0, 1, 2
+EPI_SILU, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4
+
+
+class Sy11Error(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "B", "IH", "IW", "C", "x_ld", "OH", "OW", "N", "y_ld",
+        "KH", "KW", "SH", "SW", "PH", "PW", "DH", "DW", "groups")] + [("flags", C.c_uint32)]
+
+
+_vp, _i32, _i64, _f32, _f64, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32
+_dp = C.POINTER(ConvDesc)
+
+# name -> argtypes (restype is int unless noted); the single source the symbol-export test checks against sy11.h
+SIGNATURES = {
+    "sy11_conv2d_fwd": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sy11_conv2d_dgrad": [_dp, _vp, _i32, _vp, _vp, _vp],
+    "sy11_conv2d_wgrad": [_dp, _vp, _vp, _i32, _vp, _vp],
+    "sy11_weight_transpose": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "sy11_stem_conv_fwd": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sy11_stem_conv_wgrad": [_dp, _vp, _vp, _i32, _vp, _vp],
+    "sy11_bn_finalize": [_i32, _f64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sy11_bn_act_fwd": [_i32, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp],
+    "sy11_bn_act_bwd_reduce": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "sy11_bn_act_bwd_apply": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                              _i32, _vp, _vp, _vp],
+    "sy11_copy2d": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
+    "sy11_upsample2x_fwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp],
+    "sy11_upsample2x_bwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
+    "sy11_maxpool5_fwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp],
+    "sy11_maxpool5_bwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp],
+    "sy11_cast": [_i32, _i32, _i64, _vp, _vp, _vp],
+    "sy11_attention_fwd": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp],
+    "sy11_attention_bwd": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
+    "sy11_detect_decode": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sy11_nms_sorted": [_i32, _vp, _f32, _vp, _vp, _vp],
+    "sy11_stft_logmel": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "sy11_stft_minmax_init": [_i32, _vp, _vp],
+    "sy11_stft_normalize": [_i32, _i32, _i32, _vp, _vp, _vp, _vp],
+}
+OTHER = {"sy11_version": ([], C.c_int), "sy11_last_error": ([], C.c_char_p),
+         "sy11_nms_workspace_bytes": ([_i32], C.c_size_t)}
+
+_lib = None
+
+
+def load():
+    """Load libsy11.so once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise Sy11Error(f"libsy11.so not found at {LIB_PATH}: build it with "
+                        f"`make -C spectrogram-yolov11_amd/csrc` (or __graft_entry__.build()). "
+                        f"There is no CPU / PyTorch fallback for the hot path.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, (args, res) in OTHER.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sy11_last_error()
+        raise Sy11Error(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,258 @@
+"""Tensor-level wrappers over the C-ABI (sy11._lib): build descriptors from torch tensors, pass raw device
+pointers + the current HIP stream.  torch is plumbing only (memory, streams); every computation is a libsy11 kernel.
+
+An NHWC *view* is a torch tensor of shape (B, H, W, C) whose strides are (H*W*ld, W*ld, ld, 1): a channel slice
+``buf[..., a:b]`` of a contiguous NHWC buffer qualifies (ld = buf.shape[-1]) — concat by pointer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EPI_ACCUM, EPI_OUT_F32, EPI_SILU, ConvDesc, call
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+def dt_code(t: torch.dtype) -> int:
+    try:
+        return _DT[t]
+    except KeyError:
+        raise _lib.Sy11Error(f"unsupported dtype {t}") from None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.Sy11Error("sy11 ops need tensors on the MI355X (cuda) device; there is no CPU path")
+
+
+def view_ld(t: torch.Tensor) -> int:
+    """Pixel stride of an NHWC view; validates the stride pattern."""
+    if t.dim() != 4:
+        raise _lib.Sy11Error(f"expected a 4-d NHWC view, got shape {tuple(t.shape)}")
+    B, H, W, Cn = t.shape
+    ld = t.stride(2) if W > 1 else (t.stride(1) // max(W, 1) if H > 1 else max(t.stride(0) // max(H * W, 1), Cn))
+    ok = (Cn == 1 or t.stride(3) == 1) and (W == 1 or t.stride(2) == ld) and (H == 1 or t.stride(1) == W * ld) \
+        and (B == 1 or t.stride(0) == H * W * ld) and ld >= Cn
+    if not ok:
+        raise _lib.Sy11Error(f"not an NHWC view: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld
+
+
+def nhwc_empty(B, H, W, Cn, dtype, device):
+    return torch.empty((B, H, W, Cn), dtype=dtype, device=device)
+
+
+def conv_out_hw(H, W, k, s, p, d=1):
+    return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def _desc(x_shape, x_ld, y_shape, y_ld, dtype, k, s, p, d, groups, flags):
+    B, IH, IW, Cn = x_shape
+    _, OH, OW, N = y_shape
+    kh, kw = (k, k) if isinstance(k, int) else k
+    return ConvDesc(dt_code(dtype), B, IH, IW, Cn, x_ld, OH, OW, N, y_ld, kh, kw, s, s, p, p, d, d, groups, flags)
+
+
+def filter_krsc(w: torch.Tensor) -> torch.Tensor:
+    """OIHW parameter -> memory [O][KH][KW][I].  Free when the parameter is kept in channels_last format."""
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv2d_fwd(x, w_krsc, y, k, s=1, p=0, d=1, groups=1, bias=None, stats=None, silu=False, out_f32=False):
+    """x, y: NHWC views; w_krsc: contiguous [N][KH][KW][C/groups]; stats: (sum, sumsq) f32[N] accumulated into."""
+    _need_gpu(x, w_krsc, y, bias)
+    flags = (EPI_SILU if silu else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    dsc = _desc(x.shape, view_ld(x), y.shape, view_ld(y), x.dtype, k, s, p, d, groups, flags)
+    call("sy11_conv2d_fwd", C.byref(dsc), _p(x), _p(w_krsc), _p(bias), _p(y), _p(stats[0]) if stats else None,
+         _p(stats[1]) if stats else None, _stream())
+    return y
+
+
+def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:
+    N, KH, KW, Cn = w_krsc.shape
+    wt = torch.empty((Cn, KH, KW, N), dtype=w_krsc.dtype, device=w_krsc.device)
+    call("sy11_weight_transpose", dt_code(w_krsc.dtype), N, KH * KW, Cn, _p(w_krsc), _p(wt), _stream())
+    return wt
+
+
+def conv2d_dgrad(dy, w_or_wt, dx, y_shape, k, s=1, p=0, d=1, groups=1, accumulate=False):
+    """dx (NHWC view of the conv INPUT shape) = conv^T(dy).  groups==1: pass the tap-transposed filter."""
+    _need_gpu(dy, w_or_wt, dx)
+    dsc = _desc(dx.shape, view_ld(dx), y_shape, y_shape[-1], dy.dtype, k, s, p, d, groups, EPI_ACCUM if accumulate else 0)
+    call("sy11_conv2d_dgrad", C.byref(dsc), _p(dy), view_ld(dy), _p(w_or_wt), _p(dx), _stream())
+    return dx
+
+
+def conv2d_wgrad(x, dy, dw_f32, k, s=1, p=0, d=1, groups=1):
+    """dw_f32 ([N][KH][KW][C/groups], f32) += x (*) dy."""
+    _need_gpu(x, dy, dw_f32)
+    if dw_f32.dtype != torch.float32 or not dw_f32.is_contiguous():
+        raise _lib.Sy11Error("conv2d_wgrad: dw must be a contiguous f32 tensor")
+    dsc = _desc(x.shape, view_ld(x), dy.shape, view_ld(dy), x.dtype, k, s, p, d, groups, 0)
+    call("sy11_conv2d_wgrad", C.byref(dsc), _p(x), _p(dy), view_ld(dy), _p(dw_f32), _stream())
+    return dw_f32
+
+
+def stem_conv_fwd(x_nchw, w_krsc, y, s=2, p=1, bias=None, stats=None, silu=False):
+    _need_gpu(x_nchw, w_krsc, y)
+    if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or x_nchw.shape[1] != 3:
+        raise _lib.Sy11Error("stem_conv_fwd: x must be a contiguous NCHW f32 image with 3 channels")
+    B, _, IH, IW = x_nchw.shape
+    dsc = _desc((B, IH, IW, 3), 3, y.shape, view_ld(y), y.dtype, 3, s, p, 1, 1, EPI_SILU if silu else 0)
+    call("sy11_stem_conv_fwd", C.byref(dsc), _p(x_nchw), _p(w_krsc), _p(bias), _p(y), _p(stats[0]) if stats else None,
+         _p(stats[1]) if stats else None, _stream())
+    return y
+
+
+def stem_conv_wgrad(x_nchw, dy, dw_f32, s=2, p=1):
+    _need_gpu(x_nchw, dy, dw_f32)
+    B, _, IH, IW = x_nchw.shape
+    dsc = _desc((B, IH, IW, 3), 3, dy.shape, view_ld(dy), dy.dtype, 3, s, p, 1, 1, 0)
+    call("sy11_stem_conv_wgrad", C.byref(dsc), _p(x_nchw), _p(dy), view_ld(dy), _p(dw_f32), _stream())
+    return dw_f32
+
+
+def _mc(t):
+    B, H, W, Cn = t.shape
+    return B * H * W, Cn
+
+
+def bn_finalize(count, ssum, ssq, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift):
+    call("sy11_bn_finalize", gamma.numel(), float(count), _p(ssum), _p(ssq), _p(gamma), _p(beta), eps, momentum,
+         _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
+
+
+def bn_act_fwd(y, scale, shift, z, silu=True, res=None):
+    _need_gpu(y, z, res)
+    M, Cn = _mc(y)
+    call("sy11_bn_act_fwd", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(scale), _p(shift), int(silu), _p(res),
+         view_ld(res) if res is not None else 0, _p(z), view_ld(z), _stream())
+    return z
+
+
+def bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, silu, sum_g, sum_gx):
+    M, Cn = _mc(y)
+    call("sy11_bn_act_bwd_reduce", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
+         _p(scale), _p(shift), int(silu), _p(sum_g), _p(sum_gx), _stream())
+
+
+def bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, dy, dgamma, dbeta):
+    M, Cn = _mc(y)
+    call("sy11_bn_act_bwd_apply", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
+         _p(scale), _p(shift), _p(gamma), int(silu), _p(sum_g), _p(sum_gx), _p(dy), view_ld(dy), _p(dgamma), _p(dbeta),
+         _stream())
+
+
+def copy2d(src, dst, accumulate=False):
+    _need_gpu(src, dst)
+    M, Cn = _mc(src)
+    if tuple(dst.shape) != tuple(src.shape) or dst.dtype != src.dtype:
+        raise _lib.Sy11Error(f"copy2d: shape/dtype mismatch {tuple(src.shape)} vs {tuple(dst.shape)}")
+    call("sy11_copy2d", dt_code(src.dtype), M, Cn, _p(src), view_ld(src), _p(dst), view_ld(dst), int(accumulate), _stream())
+    return dst
+
+
+def upsample2x_fwd(x, y):
+    B, H, W, Cn = x.shape
+    call("sy11_upsample2x_fwd", dt_code(x.dtype), B, H, W, Cn, _p(x), view_ld(x), _p(y), view_ld(y), _stream())
+    return y
+
+
+def upsample2x_bwd(dy, dx, accumulate=False):
+    B, H, W, Cn = dx.shape
+    call("sy11_upsample2x_bwd", dt_code(dx.dtype), B, H, W, Cn, _p(dy), view_ld(dy), _p(dx), view_ld(dx), int(accumulate),
+         _stream())
+    return dx
+
+
+def maxpool5_fwd(x, y, idx):
+    B, H, W, Cn = x.shape
+    call("sy11_maxpool5_fwd", dt_code(x.dtype), B, H, W, Cn, _p(x), view_ld(x), _p(y), view_ld(y), _p(idx), _stream())
+    return y
+
+
+def maxpool5_bwd(dy, idx, dx, accumulate=False):
+    B, H, W, Cn = dx.shape
+    call("sy11_maxpool5_bwd", dt_code(dx.dtype), B, H, W, Cn, _p(dy), view_ld(dy), _p(idx), _p(dx), view_ld(dx),
+         int(accumulate), _stream())
+    return dx
+
+
+def attention_fwd(qkv, heads, kd, hd, o, p):
+    B, H, W, _ = qkv.shape
+    call("sy11_attention_fwd", dt_code(qkv.dtype), B, H * W, heads, kd, hd, _p(qkv), view_ld(qkv), _p(o), view_ld(o), _p(p),
+         _stream())
+    return o
+
+
+def attention_bwd(qkv, heads, kd, hd, p, d_o, dqkv, ws):
+    B, H, W, _ = qkv.shape
+    call("sy11_attention_bwd", dt_code(qkv.dtype), B, H * W, heads, kd, hd, _p(qkv), view_ld(qkv), _p(p), _p(d_o),
+         view_ld(d_o), _p(dqkv), view_ld(dqkv), _p(ws), _stream())
+    return dqkv
+
+
+def detect_decode(maps, strides, nc):
+    """maps: list of contiguous NHWC f32 (B, H, W, 64+nc) -> (B, 4+nc, A) f32."""
+    _need_gpu(*maps)
+    nl = len(maps)
+    B = maps[0].shape[0]
+    for m in maps:
+        if m.dtype != torch.float32 or not m.is_contiguous() or m.shape[-1] != 64 + nc:
+            raise _lib.Sy11Error("detect_decode: maps must be contiguous NHWC f32 with 64+nc channels")
+    A = sum(m.shape[1] * m.shape[2] for m in maps)
+    out = torch.empty((B, 4 + nc, A), dtype=torch.float32, device=maps[0].device)
+    ptrs = (C.c_void_p * nl)(*[m.data_ptr() for m in maps])
+    hs = (C.c_int32 * nl)(*[m.shape[1] for m in maps])
+    ws = (C.c_int32 * nl)(*[m.shape[2] for m in maps])
+    st = (C.c_float * nl)(*[float(s) for s in strides])
+    call("sy11_detect_decode", B, nc, nl, C.cast(ptrs, C.c_void_p), C.cast(hs, C.c_void_p), C.cast(ws, C.c_void_p),
+         C.cast(st, C.c_void_p), _p(out), _stream())
+    return out
+
+
+def nms_sorted(boxes_sorted: torch.Tensor, iou_thres: float) -> torch.Tensor:
+    """boxes sorted by (score desc, index asc), (n,4) f32 contiguous -> bool keep mask (n,)."""
+    _need_gpu(boxes_sorted)
+    n = boxes_sorted.shape[0]
+    keep = torch.zeros((n,), dtype=torch.uint8, device=boxes_sorted.device)
+    if n == 0:
+        return keep.bool()
+    b = boxes_sorted.contiguous().float()
+    ws = torch.empty((_lib.load().sy11_nms_workspace_bytes(n) // 8,), dtype=torch.int64, device=b.device)
+    call("sy11_nms_sorted", n, _p(b), float(iou_thres), _p(ws), _p(keep), _stream())
+    return keep.bool()
+
+
+def stft_logmel(iq, window, mel_start, mel_w, n_fft, hop, n_frames, n_mel):
+    """iq: (B, L) complex64 -> (db (B, frames, n_mel) f32, minmax (B, 2) f32)."""
+    _need_gpu(iq, window, mel_start, mel_w)
+    if iq.dtype != torch.complex64 or not iq.is_contiguous():
+        raise _lib.Sy11Error("stft_logmel: iq must be contiguous complex64")
+    B, L = iq.shape
+    db = torch.empty((B, n_frames, n_mel), dtype=torch.float32, device=iq.device)
+    mm = torch.empty((B, 2), dtype=torch.float32, device=iq.device)
+    call("sy11_stft_minmax_init", B, _p(mm), _stream())
+    call("sy11_stft_logmel", B, L, n_fft, hop, n_frames, n_mel, C.c_void_p(torch.view_as_real(iq).data_ptr()), _p(window),
+         _p(mel_start), _p(mel_w), mel_w.shape[1], _p(db), _p(mm), _stream())
+    return db, mm
+
+
+def stft_normalize(db, mm):
+    B, n_frames, n_mel = db.shape
+    img = torch.empty((B, 3, n_mel, n_frames), dtype=torch.float32, device=db.device)
+    call("sy11_stft_normalize", B, n_mel, n_frames, _p(db), _p(mm), _p(img), _stream())
+    return img

@@ -1,0 +1,316 @@
+"""GPU parity of every libsy11 kernel (through the C-ABI) against a CPU fp32 reference of the same op.
+
+Tolerances: f32 kernels use exact-f32 MFMA (k-ordered fmaf chains) -> 2e-5 relative to the output scale;
+f16/bf16 inputs are rounded once (operands) with f32 accumulation -> 4e-3 / 3e-2 of the output scale.
+Index outputs (max-pool argmax, NMS keep) are compared bit-exactly.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}
+
+
+def ops():
+    from sy11 import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def nhwc(t_nchw, dtype, pad_c=0):
+    """NCHW cpu f32 -> NHWC device view (optionally inside a wider buffer to exercise ld > C)."""
+    B, Cn, H, W = t_nchw.shape
+    buf = torch.zeros(B, H, W, Cn + pad_c, dtype=dtype, device=DEV)
+    v = buf[..., pad_c // 2: pad_c // 2 + Cn] if pad_c else buf
+    v.copy_(t_nchw.permute(0, 2, 3, 1).to(DEV, dtype))
+    return v
+
+
+def to_nchw(v):
+    return v.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, dtype, what, mult=1.0):
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= TOL[dtype] * mult * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} ({dtype})"
+
+
+def q(t, dtype):
+    """Round a cpu f32 tensor through dtype (what the kernel's operands see)."""
+    return t.to(dtype).float()
+
+
+CONV_CASES = [
+    # B, C, H, W, N, k, s, pad_c
+    (2, 32, 9, 11, 64, 1, 1, 0),
+    (2, 64, 8, 8, 48, 3, 1, 32),
+    (1, 16, 13, 10, 32, 3, 2, 0),
+    (3, 96, 6, 7, 160, 3, 1, 16),
+    (2, 128, 8, 8, 256, 1, 1, 0),
+    (2, 64, 20, 20, 16, 3, 2, 64),
+    (1, 8, 5, 5, 8, 3, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    o = ops()
+    B, Cn, H, W, N, k, s, pad_c = case
+    if dtype != torch.float32 and (Cn % 8 or N % 8):
+        pytest.skip("16-bit path needs channels % 8 == 0")
+    p = k // 2
+    x = rnd(B, Cn, H, W, seed=1)
+    w = rnd(N, Cn, k, k, seed=2, scale=1.0 / math.sqrt(Cn * k * k))
+    bias = rnd(N, seed=3)
+    xq, wq = q(x, dtype), q(w, dtype)
+    OH, OW = o.conv_out_hw(H, W, k, s, p)
+    xv = nhwc(x, dtype, pad_c)
+    wk = wq.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    # forward: raw + stats
+    y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
+    ssum = torch.zeros(N, device=DEV)
+    ssq = torch.zeros(N, device=DEV)
+    o.conv2d_fwd(xv, wk, y, k, s, p, stats=(ssum, ssq))
+    ref = F.conv2d(xq, wq, None, s, p)
+    close(to_nchw(y), ref, dtype, "conv fwd")
+    close(ssum.cpu(), ref.sum((0, 2, 3)), dtype, "conv stats sum", mult=4 * math.sqrt(B * OH * OW))
+    close(ssq.cpu(), (ref * ref).sum((0, 2, 3)), dtype, "conv stats sq", mult=4)
+    # forward: bias + silu epilogue into a channel slice, f32 output flag
+    ybuf = torch.zeros(B, OH, OW, N + 16, dtype=dtype, device=DEV)
+    o.conv2d_fwd(xv, wk, ybuf[..., 8:8 + N], k, s, p, bias=bias.to(DEV), silu=True)
+    close(to_nchw(ybuf[..., 8:8 + N]), F.silu(ref + bias.view(1, -1, 1, 1)), dtype, "conv fwd bias+silu slice")
+    assert ybuf[..., :8].abs().max().item() == 0 and ybuf[..., 8 + N:].abs().max().item() == 0
+    y32 = torch.empty(B, OH, OW, N, dtype=torch.float32, device=DEV)
+    o.conv2d_fwd(xv, wk, y32, k, s, p, bias=bias.to(DEV), out_f32=True)
+    close(to_nchw(y32), ref + bias.view(1, -1, 1, 1), dtype, "conv fwd f32 out")
+    # dgrad (+ accumulate)
+    dy = rnd(B, N, OH, OW, seed=4)
+    dyq = q(dy, dtype)
+    dyv = nhwc(dy, dtype, 16 if dtype != torch.float32 else 8)
+    wt = o.weight_transpose(wk)
+    assert torch.equal(wt.cpu(), wk.cpu().permute(3, 1, 2, 0).contiguous())
+    dx = torch.zeros(B, H, W, Cn, dtype=dtype, device=DEV)
+    o.conv2d_dgrad(dyv, wt, dx, (B, OH, OW, N), k, s, p, accumulate=(s > 1))
+    ref_dx = torch.nn.grad.conv2d_input((B, Cn, H, W), wq, dyq, s, p)
+    close(to_nchw(dx), ref_dx, dtype, "conv dgrad")
+    o.conv2d_dgrad(dyv, wt, dx, (B, OH, OW, N), k, s, p, accumulate=True)
+    close(to_nchw(dx), 2 * ref_dx, dtype, "conv dgrad accumulate", mult=2)
+    # wgrad (accumulates into f32)
+    dw = torch.zeros(N, k, k, Cn, dtype=torch.float32, device=DEV)
+    o.conv2d_wgrad(xv, dyv, dw, k, s, p)
+    ref_dw = torch.nn.grad.conv2d_weight(xq, (N, Cn, k, k), dyq, s, p)
+    close(dw.cpu().permute(0, 3, 1, 2), ref_dw, torch.float32, "conv wgrad", mult=8)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("Cn,H,W", [(64, 8, 8), (24, 7, 5), (5, 6, 6)])
+def test_depthwise_conv(Cn, H, W, dtype):
+    o = ops()
+    B, k, p = 2, 3, 1
+    x, w, dy = rnd(B, Cn, H, W, seed=1), rnd(Cn, 1, k, k, seed=2, scale=0.3), rnd(B, Cn, H, W, seed=3)
+    xq, wq, dyq = q(x, dtype), q(w, dtype), q(dy, dtype)
+    xv, dyv = nhwc(x, dtype), nhwc(dy, dtype)
+    wk = wq.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    y = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    ssum, ssq = torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+    o.conv2d_fwd(xv, wk, y, k, 1, p, groups=Cn, stats=(ssum, ssq))
+    ref = F.conv2d(xq, wq, None, 1, p, 1, Cn)
+    close(to_nchw(y), ref, dtype, "dw fwd")
+    close(ssum.cpu(), ref.sum((0, 2, 3)), dtype, "dw stats", mult=20)
+    dx = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    o.conv2d_dgrad(dyv, wk, dx, (B, H, W, Cn), k, 1, p, groups=Cn)
+    close(to_nchw(dx), torch.nn.grad.conv2d_input((B, Cn, H, W), wq, dyq, 1, p, 1, Cn), dtype, "dw dgrad")
+    dw = torch.zeros(Cn, k, k, 1, dtype=torch.float32, device=DEV)
+    o.conv2d_wgrad(xv, dyv, dw, k, 1, p, groups=Cn)
+    close(dw.cpu().permute(0, 3, 1, 2), torch.nn.grad.conv2d_weight(xq, (Cn, 1, k, k), dyq, 1, p, 1, Cn), torch.float32,
+          "dw wgrad", mult=8)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("N,H,W", [(16, 16, 16), (32, 21, 18)])
+def test_stem_conv(N, H, W, dtype):
+    o = ops()
+    B = 2
+    x = (rnd(B, 3, H, W, seed=1) + 1) / 2
+    w = rnd(N, 3, 3, 3, seed=2, scale=0.3)
+    wq = q(w, dtype)
+    OH, OW = o.conv_out_hw(H, W, 3, 2, 1)
+    wk = wq.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
+    ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    o.stem_conv_fwd(x.to(DEV), wk, y, 2, 1, stats=(ssum, ssq))
+    ref = F.conv2d(x, wq, None, 2, 1)
+    close(to_nchw(y), ref, dtype, "stem fwd")
+    close(ssq.cpu(), (ref * ref).sum((0, 2, 3)), dtype, "stem stats", mult=4)
+    dy = rnd(B, N, OH, OW, seed=3)
+    dw = torch.zeros(N, 3, 3, 3, dtype=torch.float32, device=DEV)
+    o.stem_conv_wgrad(x.to(DEV), nhwc(dy, dtype), dw, 2, 1)
+    close(dw.cpu().permute(0, 3, 1, 2), torch.nn.grad.conv2d_weight(x, (N, 3, 3, 3), q(dy, dtype), 2, 1), torch.float32,
+          "stem wgrad", mult=8)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("Cn,silu", [(64, True), (48, False), (5, True), (1024, True)])
+def test_batchnorm_silu_fwd_bwd(Cn, silu, dtype):
+    o = ops()
+    B, H, W = 2, 5, 7
+    M = B * H * W
+    y = rnd(B, Cn, H, W, seed=1, scale=2.0)
+    yq = q(y, dtype)
+    gamma, beta = 1 + 0.3 * rnd(Cn, seed=2), 0.2 * rnd(Cn, seed=3)
+    res = rnd(B, Cn, H, W, seed=5)
+    dz = rnd(B, Cn, H, W, seed=4)
+    rm, rv = 0.1 * rnd(Cn, seed=6), 1 + 0.2 * rnd(Cn, seed=7).abs()
+    # reference (autograd, fp32)
+    yr = yq.clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    u = F.batch_norm(yr, rm_ref, rv_ref, g_, b_, True, 0.03, 1e-3)
+    z = (F.silu(u) if silu else u) + q(res, dtype)
+    (z * q(dz, dtype)).sum().backward()
+    # device
+    f = lambda t: t.to(DEV)
+    yv, dzv, resv = nhwc(y, dtype, 8), nhwc(dz, dtype), nhwc(res, dtype)
+    ssum = yv.float().sum((0, 1, 2))
+    ssq = (yv.float() ** 2).sum((0, 1, 2))
+    mean, rstd, scale, shift = (torch.empty(Cn, device=DEV) for _ in range(4))
+    rmd, rvd = f(rm), f(rv)
+    o.bn_finalize(M, ssum, ssq, f(gamma), f(beta), 1e-3, 0.03, rmd, rvd, mean, rstd, scale, shift)
+    close(rmd.cpu(), rm_ref, torch.float32, "running_mean", mult=10)
+    close(rvd.cpu(), rv_ref, torch.float32, "running_var", mult=10)
+    zv = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    o.bn_act_fwd(yv, scale, shift, zv, silu=silu, res=resv)
+    close(to_nchw(zv), z.detach(), dtype, "bn fwd", mult=2)
+    sg, sgx = torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+    o.bn_act_bwd_reduce(yv, dzv, mean, rstd, scale, shift, silu, sg, sgx)
+    dyv = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    dg, db = torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+    o.bn_act_bwd_apply(yv, dzv, mean, rstd, scale, shift, f(gamma), silu, sg, sgx, dyv, dg, db)
+    close(db.cpu(), b_.grad, dtype, "dbeta", mult=10)
+    close(dg.cpu(), g_.grad, dtype, "dgamma", mult=10)
+    close(to_nchw(dyv), yr.grad, dtype, "bn dy", mult=6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_copy_upsample_maxpool(dtype):
+    o = ops()
+    B, Cn, H, W = 2, 40, 6, 9
+    x = rnd(B, Cn, H, W, seed=1)
+    xv = nhwc(x, dtype, 8)
+    # copy into a slice, then accumulate
+    buf = torch.zeros(B, H, W, Cn + 24, dtype=dtype, device=DEV)
+    o.copy2d(xv, buf[..., 16:16 + Cn])
+    assert torch.equal(buf[..., 16:16 + Cn], xv) and buf[..., :16].abs().max() == 0
+    o.copy2d(xv, buf[..., 16:16 + Cn], accumulate=True)
+    close(to_nchw(buf[..., 16:16 + Cn]), 2 * q(x, dtype), dtype, "copy accumulate")
+    # upsample fwd / bwd
+    up = torch.empty(B, 2 * H, 2 * W, Cn, dtype=dtype, device=DEV)
+    o.upsample2x_fwd(xv, up)
+    assert torch.equal(to_nchw(up), F.interpolate(q(x, dtype), scale_factor=2.0, mode="nearest"))
+    g = rnd(B, Cn, 2 * H, 2 * W, seed=2)
+    dx = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    o.upsample2x_bwd(nhwc(g, dtype), dx)
+    close(to_nchw(dx), F.avg_pool2d(q(g, dtype), 2) * 4, dtype, "upsample bwd")
+    # max-pool 5x5 s1 p2 with plateaus (ties): quantise the input so equal values are common
+    xt = (rnd(B, Cn, H, W, seed=3) * 3).round() / 3
+    xtv = nhwc(xt, dtype)
+    yv = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    idx = torch.empty(B, H, W, Cn, dtype=torch.uint8, device=DEV)
+    o.maxpool5_fwd(xtv, yv, idx)
+    xr = q(xt, dtype).requires_grad_(True)
+    yr = F.max_pool2d(xr, 5, 1, 2)
+    assert torch.equal(to_nchw(yv), yr.detach())
+    gp = rnd(B, Cn, H, W, seed=4)
+    yr.backward(q(gp, dtype))
+    dxp = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    o.maxpool5_bwd(nhwc(gp, dtype), idx, dxp)
+    close(to_nchw(dxp), xr.grad, dtype, "maxpool bwd (tie routing)", mult=4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("B,H,W,heads", [(2, 6, 5, 2), (1, 20, 20, 4), (2, 3, 3, 1)])
+def test_attention_fwd_bwd(B, H, W, heads, dtype):
+    o = ops()
+    kd, hd = 32, 64
+    N = H * W
+    Cq = heads * (2 * kd + hd)
+    qkv = rnd(B, Cq, H, W, seed=1)
+    qq = q(qkv, dtype).requires_grad_(True)
+    qh, kh, vh = qq.view(B, heads, 2 * kd + hd, N).split([kd, kd, hd], 2)
+    attn = ((qh.transpose(-2, -1) @ kh) * kd ** -0.5).softmax(-1)
+    oref = (vh @ attn.transpose(-2, -1)).view(B, heads * hd, H, W)
+    do = rnd(B, heads * hd, H, W, seed=2)
+    (oref * q(do, dtype)).sum().backward()
+    qv = nhwc(qkv, dtype)
+    ov = torch.empty(B, H, W, heads * hd, dtype=dtype, device=DEV)
+    p = torch.empty(B, heads, N, N, dtype=torch.float32, device=DEV)
+    o.attention_fwd(qv, heads, kd, hd, ov, p)
+    close(p.cpu(), attn.detach(), dtype, "attention P", mult=4)
+    close(to_nchw(ov), oref.detach(), dtype, "attention o", mult=4)
+    dq = torch.empty(B, H, W, Cq, dtype=dtype, device=DEV)
+    ws = torch.empty(B, heads, N, N, dtype=torch.float32, device=DEV)
+    o.attention_bwd(qv, heads, kd, hd, p, nhwc(do, dtype), dq, ws)
+    close(to_nchw(dq), qq.grad, dtype, "attention dqkv", mult=8)
+
+
+def test_detect_decode_matches_oracle():
+    from oracle import yolo11_ref as R
+    o = ops()
+    nc, B = 7, 2
+    maps = [rnd(B, 64 + nc, h, w, seed=i, scale=3.0) for i, (h, w) in enumerate([(8, 6), (4, 3), (2, 2)])]
+    ref = R.detect_decode(maps, (8.0, 16.0, 32.0), nc)
+    dev = [m.permute(0, 2, 3, 1).contiguous().to(DEV) for m in maps]
+    got = o.detect_decode(dev, (8.0, 16.0, 32.0), nc)
+    close(got.cpu(), ref, torch.float32, "detect decode", mult=4)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 700, 3000])
+def test_nms_bit_exact_vs_oracle(n):
+    from oracle import nms_ref
+    o = ops()
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(0, 300, (n, 2)).astype(np.float32)
+    wh = rng.uniform(4, 90, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], 1)
+    scores = rng.uniform(0, 1, n).astype(np.float32)
+    if n > 10:
+        scores[5] = scores[3]            # a tie: lower original index must win
+        boxes[5] = boxes[3]
+    ref_keep = nms_ref.nms_core(boxes, scores, 0.6)
+    order = torch.sort(torch.from_numpy(scores), descending=True, stable=True).indices
+    keep = o.nms_sorted(torch.from_numpy(boxes)[order].to(DEV), 0.6)
+    got = order[keep.cpu()].numpy()
+    assert np.array_equal(got, ref_keep)
+
+
+def test_stft_logmel_matches_oracle():
+    from oracle import stft_ref as S
+    o = ops()
+    iq = S.synthetic_iq(2, seed=1)
+    ref_db = S.logmel_db(iq)                       # (B, mel, frames)
+    start, wts = S.mel_table()
+    win = torch.hann_window(S.N_FFT, periodic=True)
+    db, mm = o.stft_logmel(iq.to(DEV), win.to(DEV), torch.from_numpy(start).to(DEV), torch.from_numpy(wts).to(DEV),
+                           S.N_FFT, S.HOP, S.N_FRAMES, S.N_MEL)
+    got = db.cpu().transpose(1, 2)
+    # dB domain: f32 FFT of 1024 points -> ~1e-6 relative power error -> < 1e-3 dB except in deep nulls
+    err = (got - ref_db).abs()
+    assert err.max().item() < 5e-2 and err.mean().item() < 1e-4, (err.max().item(), err.mean().item())
+    assert torch.allclose(mm[:, 0].cpu(), got.amin((1, 2))) and torch.allclose(mm[:, 1].cpu(), got.amax((1, 2)))
+    img = o.stft_normalize(db, mm).cpu()
+    ref_img = S.spectrogram_image(iq)
+    assert img.shape == (2, 3, 640, 640)
+    assert (img - ref_img).abs().max().item() < 2e-3
+    assert img.min().item() == 0.0 and abs(img.max().item() - 1.0) < 1e-6
