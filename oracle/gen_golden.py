@@ -67,7 +67,7 @@ def summarize(store: dict, name: str, t: torch.Tensor):
 def main():
     import_reference()
     sys.path.insert(0, str(ROOT))
-    from oracle.yolo11_ref import closed_form, closed_form_state_dict
+    from oracle.yolo11_ref import closed_form, closed_form_state_dict, empty_state_dict, resolve_graph, seeded_image, seeded_state_dict
     from ultralytics.nn.modules import block as B, conv as C, head as H
     from ultralytics.nn.tasks import DetectionModel, yaml_model_load
     from ultralytics.utils import IterableSimpleNamespace
@@ -151,9 +151,11 @@ def main():
     nc = 4
     model = DetectionModel(d, ch=3, nc=nc, verbose=False)
     model.args = IterableSimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
-    model.load_state_dict(closed_form_state_dict(model.state_dict()))
+    tiny_sd = lambda: seeded_state_dict(empty_state_dict(resolve_graph("t", nc=nc)), seed=0)
+    assert set(tiny_sd().keys()) == set(model.state_dict().keys())
+    model.load_state_dict(tiny_sd())
     Bsz, S = 2, 64
-    img = closed_form("in.model_t", (Bsz, 3, S, S), "input")
+    img = seeded_image((Bsz, 3, S, S), seed=5)
     batch = {
         "img": img,
         "batch_idx": torch.tensor([0, 0, 1, 1, 1], dtype=torch.float32),
@@ -169,7 +171,7 @@ def main():
         summarize(store, f"train.map{i}", mp)
     model.zero_grad()
     # fresh BN buffers again so loss forward sees the same statistics state as a single train step would
-    model.load_state_dict(closed_form_state_dict(model.state_dict()))
+    model.load_state_dict(tiny_sd())
     crit = model.init_criterion()
     model.criterion = crit
     # capture TAL outputs
@@ -204,7 +206,7 @@ def main():
     for k in ("model.0.bn.running_mean", "model.0.bn.running_var", "model.22.cv2.bn.running_var"):
         summarize(store, "buf." + k, model.state_dict()[k])
     # eval + fused eval
-    model.load_state_dict(closed_form_state_dict(model.state_dict()))
+    model.load_state_dict(tiny_sd())
     model.eval()
     with torch.no_grad():
         y, maps = model(img)

@@ -345,6 +345,34 @@ def closed_form_state_dict(template: dict):
     return out
 
 
+def seeded_state_dict(template: dict, seed: int = 0):
+    """Seeded-random (CPU generator) values for every float entry except the frozen DFL weight.
+
+    Used for END-TO-END fixtures: the sinusoidal closed form above yields near-degenerate channels, which makes
+    train-mode BatchNorm over tiny batches ill-conditioned (fp32 vs fp64 of the same graph differ by 3e-2), so no
+    implementation could be compared at 1e-3.  He-style random filters keep fp32-vs-fp64 at ~1e-4."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in template.items():
+        if not v.dtype.is_floating_point or ".dfl." in k:
+            out[k] = v.clone()
+        elif k.endswith("running_var"):
+            out[k] = 0.5 + torch.rand(v.shape, generator=g)
+        elif k.endswith("running_mean"):
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif k.endswith("bn.weight"):
+            out[k] = 1 + 0.2 * torch.randn(v.shape, generator=g)
+        elif k.endswith("bias"):
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            out[k] = torch.randn(v.shape, generator=g) * math.sqrt(2.0 / v[0].numel())
+    return out
+
+
+def seeded_image(shape, seed: int = 5):
+    return torch.rand(shape, generator=torch.Generator().manual_seed(seed))
+
+
 def empty_state_dict(layers):
     """Allocate a zero state_dict with the reference's keys and shapes for a resolved graph."""
     sd = {}

@@ -1,0 +1,245 @@
+"""Execution engine: NHWC activations, an explicit backward tape and the autograd bridge.
+
+Why not torch autograd per op?  The hot path writes producers straight into channel slices of concat buffers,
+accumulates gradients in place into slices, and keeps raw conv outputs (not BN/SiLU outputs) for backward.  An
+explicit tape gives that control; ONE ``torch.autograd.Function`` (``EngineFn``) exposes a whole module (or the whole
+DetectionModel) to torch so ``loss.backward()``, ``GradScaler`` and optimizers work unchanged
+(engine/trainer.py:378-393 surface).
+
+Parameter gradients are written by the kernels directly into views of ONE flat f32 buffer (``GradStore``), which is
+what the data-parallel step all-reduces (one RCCL call over xGMI instead of per-tensor buckets).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+
+class Act:
+    """An NHWC activation view plus its (lazily allocated) gradient.  Children are channel slices of a root buffer."""
+
+    __slots__ = ("_data", "root", "c0", "_grad", "_ready", "raw", "req", "_dtype")
+
+    def __init__(self, data: Optional[torch.Tensor], root: Optional["Act"] = None, c0: int = 0,
+                 raw: Optional[torch.Tensor] = None, req: bool = True, dtype=None):
+        self._data = data
+        self.root = root
+        self.c0 = c0
+        self._grad = None
+        self._ready = False
+        self.raw = raw          # original NCHW f32 image (the stem kernel reads it directly; NHWC copy made lazily)
+        self.req = req          # does anything upstream want this activation's gradient?
+        self._dtype = dtype
+
+    @property
+    def data(self) -> torch.Tensor:
+        if self._data is None:
+            t = self.raw
+            v = torch.empty((t.shape[0], t.shape[2], t.shape[3], t.shape[1]), dtype=self._dtype, device=t.device)
+            v.copy_(t.permute(0, 2, 3, 1))
+            self._data = v
+        return self._data
+
+    @property
+    def shape(self):
+        if self._data is None:
+            t = self.raw
+            return torch.Size((t.shape[0], t.shape[2], t.shape[3], t.shape[1]))
+        return self._data.shape
+
+    @property
+    def C(self):
+        return self.shape[-1]
+
+    def slice(self, a: int, b: int) -> "Act":
+        r = self.root or self
+        return Act(self.data[..., a:b], r, self.c0 + a, req=self.req)
+
+    # ---- gradients
+    def _root_grad(self):
+        r = self.root or self
+        if r._grad is None:
+            r._grad = torch.empty(r.data.shape, dtype=r.data.dtype, device=r.data.device)
+        return r
+
+    def grad_for_write(self):
+        """-> (grad view, accumulate?).  First full-buffer writer overwrites; everything else accumulates."""
+        r = self._root_grad()
+        if r._ready:
+            acc = True
+        elif self.root is None:
+            acc = False
+        else:                       # a slice is written before the whole buffer: start from zeros
+            r._grad.zero_()
+            acc = True
+        r._ready = True
+        g = r._grad if self.root is None else r._grad[..., self.c0:self.c0 + self.C]
+        return g, acc
+
+    def grad_read(self):
+        r = self._root_grad()
+        if not r._ready:
+            r._grad.zero_()
+            r._ready = True
+        return r._grad if self.root is None else r._grad[..., self.c0:self.c0 + self.C]
+
+    def set_grad(self, g: torch.Tensor):
+        assert self.root is None
+        self._grad = g
+        self._ready = True
+
+
+class Ctx:
+    """State of one forward pass through the engine."""
+
+    def __init__(self, training: bool, record: bool, dtype: torch.dtype, device, grads: Optional["GradStore"]):
+        self.training = training
+        self.record = record          # build a backward tape
+        self.dtype = dtype
+        self.device = device
+        self.tape: List = []
+        self.grads = grads
+
+    def empty(self, B, H, W, Cn, dtype=None):
+        return torch.empty((B, H, W, Cn), dtype=dtype or self.dtype, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(shape, dtype=torch.float32, device=self.device)
+
+
+class GradStore:
+    """One flat f32 gradient buffer; every parameter's ``.grad`` is a view of it (conv filters in KRSC memory)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.flat = None
+        self.views = {}
+
+    def _build(self, device):
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            seg = self.flat[off:off + n]
+            if p.dim() == 4:
+                o, i, kh, kw = p.shape
+                v = seg.view(o, kh, kw, i).permute(0, 3, 1, 2)     # OIHW shape, channels_last memory
+            else:
+                v = seg.view(p.shape)
+            self.views[id(p)] = v
+            off += n
+
+    def begin_backward(self, device):
+        """Attach views; zero the buffer when the optimizer has cleared the grads (fresh accumulation window)."""
+        if self.flat is None or self.flat.device != device:
+            self._build(device)
+        fresh = any(p.grad is None or p.grad.data_ptr() != self.views[id(p)].data_ptr() for p in self.params)
+        if fresh:
+            self.flat.zero_()
+            for p in self.params:
+                p.grad = self.views[id(p)]
+
+    def grad_krsc(self, p: torch.nn.Parameter) -> torch.Tensor:
+        """Contiguous [O][KH][KW][I] f32 view of a conv filter's gradient."""
+        return self.views[id(p)].permute(0, 2, 3, 1)
+
+    def grad_vec(self, p: torch.nn.Parameter) -> torch.Tensor:
+        return self.views[id(p)]
+
+
+def engine_dtype(module) -> torch.dtype:
+    """Activation dtype: f16 under torch autocast (the reference's AMP, engine/trainer.py:378), else the module's own."""
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return getattr(module, "_sy11_dtype", torch.float32)
+
+
+def to_act(t: torch.Tensor, dtype) -> Act:
+    """NCHW-shaped tensor (any strides) -> NHWC Act.  A contiguous f32 3-channel image is also kept raw for the stem."""
+    if not t.is_cuda:
+        raise ops._lib.Sy11Error("sy11 modules run on the MI355X only: move the model and inputs to 'cuda' "
+                                 "(there is no CPU fallback on the hot path)")
+    if t.dtype == torch.float32 and t.shape[1] == 3 and t.is_contiguous():
+        return Act(None, raw=t, req=t.requires_grad, dtype=dtype)
+    v = t.permute(0, 2, 3, 1)
+    if v.dtype != dtype or not v.is_contiguous():
+        n = torch.empty(v.shape, dtype=dtype, device=t.device)
+        n.copy_(v)
+        v = n
+    return Act(v, req=t.requires_grad)
+
+
+def from_act(a: Act) -> torch.Tensor:
+    """NHWC Act -> NCHW-shaped tensor (channels_last strides, zero copy); non-4-d outputs pass through."""
+    return a.data.permute(0, 3, 1, 2) if a.data.dim() == 4 else a.data
+
+
+def _flatten(x):
+    if isinstance(x, (list, tuple)):
+        return list(x), True
+    return [x], False
+
+
+class EngineFn(torch.autograd.Function):
+    """Runs ``module._run`` on Acts; backward replays the tape and fills parameter grads in the GradStore."""
+
+    @staticmethod
+    def forward(ctx, module, n_in, is_list, record, dtype, *tensors):
+        ins = tensors[:n_in]
+        store = None
+        if record:
+            store = module.__dict__.get("_sy11_grads")
+            if store is None:
+                store = GradStore(module)
+                module.__dict__["_sy11_grads"] = store
+        ec = Ctx(module.training, record, dtype, ins[0].device, store)
+        acts = [to_act(t, dtype) for t in ins]
+        out = module._run(ec, acts if is_list else acts[0])
+        outs, out_list = _flatten(out)
+        ctx.ec, ctx.acts, ctx.outs, ctx.n_in = ec, acts, outs, n_in
+        ctx.n_t = len(tensors)
+        ctx.in_req = [t.requires_grad for t in ins]
+        return tuple(from_act(a) for a in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ec: Ctx = ctx.ec
+        if ec.grads is not None:
+            ec.grads.begin_backward(ec.device)
+        for a, g in zip(ctx.outs, gouts):
+            if g is None or a.data.dim() != 4:
+                continue
+            gv = g.permute(0, 2, 3, 1)
+            if gv.dtype != a.data.dtype or not gv.is_contiguous():
+                gv = gv.to(a.data.dtype).contiguous()
+            a.set_grad(gv)
+        for bw in reversed(ec.tape):
+            bw()
+        ec.tape.clear()
+        gin = []
+        for a, req in zip(ctx.acts, ctx.in_req):
+            if req:
+                g = a.grad_read().permute(0, 3, 1, 2)
+                gin.append(g.float() if g.dtype != torch.float32 else g)
+            else:
+                gin.append(None)
+        hook = module_post_backward.get(id(ec.grads)) if ec.grads is not None else None
+        if hook is not None:
+            hook(ec.grads)
+        return (None, None, None, None, None, *gin, *([None] * (ctx.n_t - ctx.n_in)))
+
+
+# GradStore id -> callable(GradStore): set by the data-parallel wrapper to all-reduce the flat gradient buffer
+module_post_backward = {}
+
+
+def run_module(module, x):
+    """nn.Module.forward for any sy11 module: tensor(s) in, tensor(s) out, differentiable through EngineFn."""
+    xs, is_list = _flatten(x)
+    params = [p for p in module.parameters()]
+    record = module.training and torch.is_grad_enabled() and any(t.requires_grad for t in (*xs, *params))
+    return EngineFn.apply(module, len(xs), is_list, record, engine_dtype(module), *xs, *params)

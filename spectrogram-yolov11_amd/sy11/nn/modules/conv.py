@@ -1,0 +1,232 @@
+"""Convolution modules with the reference's names, constructor signatures and state_dict keys
+(ultralytics/nn/modules/conv.py:56-83 autopad/Conv, :687-692 DWConv, :1810-1821 Concat), executed by libsy11.
+
+``self.conv`` / ``self.bn`` are ordinary ``nn.Conv2d`` / ``nn.BatchNorm2d`` objects used as PARAMETER HOLDERS
+(identical pickling / checkpoint layout); their ``forward`` is never called.  The filter is kept in
+channels_last memory so the kernels read [Cout][KH][KW][Cin] in place.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...engine import Act, Ctx, run_module
+
+__all__ = ("Conv", "DWConv", "Concat", "autopad")
+
+
+def autopad(k, p=None, d=1):
+    """'same' padding (conv.py:56-62)."""
+    if d > 1:
+        k = d * (k - 1) + 1 if isinstance(k, int) else [d * (x - 1) + 1 for x in k]
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+def _int(v):
+    return v[0] if isinstance(v, (tuple, list)) else v
+
+
+def working_filter(holder: nn.Module, w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[O][KH][KW][I] tensor of ``dtype`` for parameter ``w``; cached until the parameter is modified in place."""
+    key = (w._version, w.data_ptr(), dtype, w.device)
+    cache = holder.__dict__.get("_sy11_wcache")
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    k = ops.filter_krsc(w.detach())
+    if k.dtype != dtype:
+        k = k.to(dtype)
+    holder.__dict__["_sy11_wcache"] = (key, k)
+    return k
+
+
+def conv2d_bias_run(ec: Ctx, conv: nn.Conv2d, x: Act, out: Act) -> Act:
+    """Bare nn.Conv2d with bias (Detect's last 1x1 convs, head.py:44-55): writes f32 logits into ``out``."""
+    k, s, p, d = _int(conv.kernel_size), _int(conv.stride), _int(conv.padding), _int(conv.dilation)
+    w = working_filter(conv, conv.weight, ec.dtype)
+    bias = conv.bias.detach().float() if conv.bias is not None else None
+    out_f32 = out.data.dtype == torch.float32 and ec.dtype != torch.float32
+    ops.conv2d_fwd(x.data, w, out.data, k, s, p, d, 1, bias=bias, out_f32=out_f32)
+    if ec.record:
+        def bw():
+            dz = out.grad_read()
+            gs = ec.grads
+            n = dz.shape[3]
+            if conv.bias is not None and id(conv.bias) in gs.views:
+                one = torch.ones(n, device=ec.device)
+                zero = torch.zeros(n, device=ec.device)
+                scratch = torch.empty(n, device=ec.device)
+                ops.bn_act_bwd_reduce(dz, dz, zero, one, one, zero, False, gs.grad_vec(conv.bias), scratch)
+            epc = 16 // torch.empty((), dtype=ec.dtype).element_size()
+            npad = -(-n // epc) * epc
+            if npad == n and dz.dtype == ec.dtype and (dz.stride(2) * dz.element_size()) % 16 == 0:
+                dy, wk = dz, w
+            else:                                      # pad the channel count to a 16-byte multiple (e.g. nc = 2)
+                dy = torch.zeros((*dz.shape[:3], npad), dtype=ec.dtype, device=ec.device)
+                dy[..., :n].copy_(dz)
+                wk = w if npad == n else torch.zeros((npad, *w.shape[1:]), dtype=w.dtype, device=w.device)
+                if npad != n:
+                    wk[:n].copy_(w)
+            if id(conv.weight) in gs.views:
+                if npad == n:
+                    ops.conv2d_wgrad(x.data, dy, gs.grad_krsc(conv.weight), k, s, p, d, 1)
+                else:
+                    dwp = torch.zeros((npad, *w.shape[1:]), dtype=torch.float32, device=ec.device)
+                    ops.conv2d_wgrad(x.data, dy, dwp, k, s, p, d, 1)
+                    gs.grad_krsc(conv.weight).add_(dwp[:n])
+            if x.req:
+                g, acc = x.grad_for_write()
+                ops.conv2d_dgrad(dy, ops.weight_transpose(wk), g, tuple(dy.shape), k, s, p, d, 1, accumulate=acc)
+        ec.tape.append(bw)
+    return out
+
+
+class Conv(nn.Module):
+    """Conv2d + BatchNorm2d + SiLU: args (ch_in, ch_out, kernel, stride, padding, groups, dilation, activation)."""
+
+    default_act = nn.SiLU()  # shared instance, rebindable by a YAML `activation:` key (tasks.py:979-980)
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+        self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+    # ---- torch-facing API (tensor in / tensor out, differentiable)
+    def forward(self, x):
+        return run_module(self, x)[0]
+
+    def forward_fuse(self, x):
+        return run_module(self, x)[0]
+
+    # ---- engine
+    def _silu(self) -> bool:
+        if isinstance(self.act, nn.SiLU):
+            return True
+        if isinstance(self.act, nn.Identity):
+            return False
+        raise ops._lib.Sy11Error(f"activation {type(self.act).__name__} has no HIP kernel (SiLU / Identity only)")
+
+    def _run(self, ec: Ctx, x: Act, out: Act = None, res: Act = None) -> Act:
+        conv = self.conv
+        k, s, p, d, g = _int(conv.kernel_size), _int(conv.stride), _int(conv.padding), _int(conv.dilation), conv.groups
+        B, H, W, C1 = x.shape
+        N = conv.out_channels
+        OH, OW = ops.conv_out_hw(H, W, k, s, p, d)
+        silu = self._silu()
+        w = working_filter(conv, conv.weight, ec.dtype)
+        stem = x.raw is not None and C1 == 3 and k == 3 and g == 1 and d == 1 and N <= 64
+        if out is None:
+            out = Act(ec.empty(B, OH, OW, N))
+        bn = getattr(self, "bn", None)
+        if bn is None:                                   # fused Conv (BaseModel.fuse): conv + bias + act in one kernel
+            if ec.record and conv.weight.requires_grad:
+                raise ops._lib.Sy11Error("a fused Conv is inference-only (fuse_conv_and_bn makes it requires_grad=False)")
+            bias = conv.bias.detach().float() if conv.bias is not None else None
+            if stem:
+                ops.stem_conv_fwd(x.raw, w, out.data, s, p, bias=bias, silu=silu)
+            else:
+                ops.conv2d_fwd(x.data, w, out.data, k, s, p, d, g, bias=bias, silu=silu)
+            if res is not None:
+                ops.copy2d(res.data, out.data, accumulate=True)
+            return out
+        y = ec.empty(B, OH, OW, N)
+        if not ec.training:                              # eval with running statistics
+            if ec.record:
+                raise ops._lib.Sy11Error("gradients through eval-mode BatchNorm are not implemented; call model.train()")
+            scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
+            shift = (bn.bias.detach() - bn.running_mean * scale).float()
+            if stem:
+                ops.stem_conv_fwd(x.raw, w, y, s, p)
+            else:
+                ops.conv2d_fwd(x.data, w, y, k, s, p, d, g)
+            ops.bn_act_fwd(y, scale, shift, out.data, silu=silu, res=res.data if res is not None else None)
+            return out
+        st = ec.zeros(2, N)
+        if stem:
+            ops.stem_conv_fwd(x.raw, w, y, s, p, stats=(st[0], st[1]))
+        else:
+            ops.conv2d_fwd(x.data, w, y, k, s, p, d, g, stats=(st[0], st[1]))
+        v = torch.empty((4, N), dtype=torch.float32, device=ec.device)
+        mean, rstd, scale, shift = v[0], v[1], v[2], v[3]
+        gamma, beta = bn.weight.detach().float(), bn.bias.detach().float()
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        track = bn.track_running_stats and bn.running_mean is not None
+        ops.bn_finalize(B * OH * OW, st[0], st[1], gamma, beta, bn.eps, mom, bn.running_mean if track else None,
+                        bn.running_var if track else None, mean, rstd, scale, shift)
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        ops.bn_act_fwd(y, scale, shift, out.data, silu=silu, res=res.data if res is not None else None)
+        if ec.record:
+            def bw():
+                gs = ec.grads
+                dz = out.grad_read()
+                sg = ec.zeros(2, N)
+                ops.bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, silu, sg[0], sg[1])
+                dy = torch.empty_like(y)
+                has_bn = id(bn.weight) in gs.views
+                ops.bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, silu, sg[0], sg[1], dy,
+                                     gs.grad_vec(bn.weight) if has_bn else None, gs.grad_vec(bn.bias) if has_bn else None)
+                if res is not None and res.req:
+                    rg, acc = res.grad_for_write()
+                    ops.copy2d(dz, rg, accumulate=acc)
+                if id(conv.weight) in gs.views:
+                    if stem:
+                        ops.stem_conv_wgrad(x.raw, dy, gs.grad_krsc(conv.weight), s, p)
+                    else:
+                        ops.conv2d_wgrad(x.data, dy, gs.grad_krsc(conv.weight), k, s, p, d, g)
+                if x.req:
+                    gx, acc = x.grad_for_write()
+                    if g == 1:
+                        if s > 1 and k < s and not acc:
+                            gx.zero_()
+                            acc = True
+                        ops.conv2d_dgrad(dy, ops.weight_transpose(w), gx, (B, OH, OW, N), k, s, p, d, 1, accumulate=acc)
+                    else:
+                        ops.conv2d_dgrad(dy, w, gx, (B, OH, OW, N), k, s, p, d, g, accumulate=acc)
+            ec.tape.append(bw)
+        return out
+
+
+class DWConv(Conv):
+    """Depth-wise convolution (conv.py:687-692)."""
+
+    def __init__(self, c1, c2, k=1, s=1, d=1, act=True):
+        super().__init__(c1, c2, k, s, g=math.gcd(c1, c2), d=d, act=act)
+
+
+class Concat(nn.Module):
+    """Concatenate a list of tensors along ``dimension`` (conv.py:1810-1821); channel concat runs as strided copies."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        return run_module(self, x)[0]
+
+    def _run(self, ec: Ctx, xs) -> Act:
+        if self.d != 1:
+            raise ops._lib.Sy11Error("only channel concatenation (dimension=1) is on the hot path")
+        B, H, W, _ = xs[0].shape
+        out = Act(ec.empty(B, H, W, sum(a.C for a in xs)))
+        c = 0
+        parts = []
+        for a in xs:
+            sl = out.slice(c, c + a.C)
+            ops.copy2d(a.data, sl.data)
+            parts.append((a, sl))
+            c += a.C
+        if ec.record:
+            def bw():
+                for a, sl in parts:
+                    if a.req:
+                        g, acc = a.grad_for_write()
+                        ops.copy2d(sl.grad_read(), g, accumulate=acc)
+            ec.tape.append(bw)
+        return out

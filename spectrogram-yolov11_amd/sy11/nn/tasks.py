@@ -1,0 +1,269 @@
+"""Graph builder and model classes with the reference's surface (ultralytics/nn/tasks.py: BaseModel :122-327,
+DetectionModel :329-418, parse_model :963-1168, yaml_model_load :1171-1184, guess_model_scale :1187-1203).
+
+The whole layer graph executes inside ONE engine pass (``EngineFn``): activations stay NHWC on the MI355X, the
+``y[m.f]`` skip bookkeeping of ``_predict_once`` is done on engine activations, and backward is the engine's tape.
+"""
+from __future__ import annotations
+
+import ast
+import contextlib
+import math
+import re
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import yaml
+
+from .. import ops
+from ..engine import Act, Ctx, run_module
+from ..utils.torch_utils import fuse_conv_and_bn, initialize_weights, intersect_dicts
+from .modules import (C2PSA, C3, SPPF, Bottleneck, C2f, C3k, C3k2, Concat, Conv, Detect, DWConv)
+
+CFG_DIR = Path(__file__).resolve().parents[1] / "cfg" / "models"
+
+
+def make_divisible(x, divisor):
+    if isinstance(divisor, torch.Tensor):
+        divisor = int(divisor.max())
+    return math.ceil(x / divisor) * divisor
+
+
+class BaseModel(nn.Module):
+    """Base class: dict input -> loss, tensor input -> predictions (tasks.py:125-141)."""
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):
+            return self.loss(x, *args, **kwargs)
+        return self.predict(x, *args, **kwargs)
+
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        if augment or visualize or embed or profile:
+            raise NotImplementedError("augment / visualize / embed / profile are outside the hot path")
+        return self._predict_once(x)
+
+    def _predict_once(self, x, profile=False, visualize=False, embed=None):
+        """One engine pass over the whole graph."""
+        outs = run_module(self, x)
+        det = self.model[-1]
+        if isinstance(det, Detect):
+            if self.training:
+                return list(outs)
+            return outs[0], list(outs[1:])
+        return outs[0]
+
+    def _run(self, ec: Ctx, x: Act):
+        """tasks.py:174-188 on engine activations; Upsample+Concat run as 'write into the concat buffer'."""
+        y = []
+        for m in self.model:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            if isinstance(m, nn.Upsample):
+                x = _upsample_run(ec, m, x)
+            else:
+                x = m._run(ec, x)
+            y.append(x if m.i in self.save else None)
+        return x
+
+    def fuse(self, verbose=True):
+        """Fold every BatchNorm into its conv (tasks.py:223-251) -> single conv+bias+SiLU kernels."""
+        if not self.is_fused():
+            for m in self.model.modules():
+                if isinstance(m, Conv) and hasattr(m, "bn"):
+                    m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                    delattr(m, "bn")
+                    m.forward = m.forward_fuse
+        return self
+
+    def is_fused(self, thresh=10):
+        bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
+        return sum(isinstance(v, bn) for v in self.modules()) < thresh
+
+    def info(self, detailed=False, verbose=True, imgsz=640):
+        n_p = sum(x.numel() for x in self.parameters())
+        n_g = sum(x.numel() for x in self.parameters() if x.requires_grad)
+        n_l = len(list(self.modules()))
+        return n_l, n_p, n_g
+
+    def _apply(self, fn):
+        self = super()._apply(fn)
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.stride = fn(m.stride)
+            m.anchors = fn(m.anchors)
+            m.strides = fn(m.strides)
+        return self
+
+    def load(self, weights, verbose=True):
+        model = weights["model"] if isinstance(weights, dict) else weights
+        csd = model.float().state_dict()
+        csd = intersect_dicts(csd, self.state_dict())
+        self.load_state_dict(csd, strict=False)
+
+    def loss(self, batch, preds=None):
+        if getattr(self, "criterion", None) is None:
+            self.criterion = self.init_criterion()
+        preds = self.forward(batch["img"]) if preds is None else preds
+        return self.criterion(preds, batch)
+
+    def init_criterion(self):
+        raise NotImplementedError("compute_loss() needs to be implemented by task heads")
+
+
+def _upsample_run(ec: Ctx, m: nn.Upsample, x: Act) -> Act:
+    if m.mode != "nearest" or float(m.scale_factor) != 2.0:
+        raise ops._lib.Sy11Error("only nn.Upsample(None, 2, 'nearest') has a HIP kernel")
+    B, H, W, Cn = x.shape
+    out = Act(ec.empty(B, 2 * H, 2 * W, Cn))
+    ops.upsample2x_fwd(x.data, out.data)
+    if ec.record:
+        def bw():
+            if x.req:
+                g, acc = x.grad_for_write()
+                ops.upsample2x_bwd(out.grad_read(), g, accumulate=acc)
+        ec.tape.append(bw)
+    return out
+
+
+class DetectionModel(BaseModel):
+    """YOLO detection model."""
+
+    def __init__(self, cfg="yolo11n.yaml", ch=3, nc=None, verbose=True):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if nc and nc != self.yaml["nc"]:
+            self.yaml["nc"] = nc
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self.names = {i: f"{i}" for i in range(self.yaml["nc"])}
+        self.inplace = self.yaml.get("inplace", True)
+        self.end2end = getattr(self.model[-1], "end2end", False)
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.inplace = self.inplace
+            # The reference discovers the strides with a train-mode dry run on zeros(1, ch, 256, 256) (tasks.py:359-367).
+            # There is no CPU execution path here, so they are derived from the graph (product of conv strides /
+            # upsample factors along each Detect input) — same values; the dry run's side effect on the BN running
+            # buffers (one momentum-0.1 update from a zero image) is deliberately NOT reproduced.
+            m.stride = torch.tensor(_graph_strides(self.model, self.save))
+            self.stride = m.stride
+            m.bias_init()
+        else:
+            self.stride = torch.Tensor([32])
+        initialize_weights(self)
+
+    def init_criterion(self):
+        from ..utils.loss import v8DetectionLoss
+        return v8DetectionLoss(self)
+
+
+def _graph_strides(model, save):
+    """Down-sampling factor of every Detect input, from the layer graph."""
+    s = []
+    for m in model:
+        prev = s[-1] if s else 1.0
+        f = m.f
+        src = prev if f == -1 else (s[f] if isinstance(f, int) else None)
+        if isinstance(m, Detect):
+            return [float(s[j]) for j in f]
+        if isinstance(m, Conv):
+            s.append(src * m.conv.stride[0])
+        elif isinstance(m, nn.Upsample):
+            s.append(src / float(m.scale_factor))
+        elif isinstance(m, Concat):
+            vals = [prev if j == -1 else s[j] for j in f]
+            assert len(set(vals)) == 1, "Concat inputs have different strides"
+            s.append(vals[0])
+        else:
+            s.append(src)
+    raise ValueError("no Detect layer")
+
+
+_MODULES = {"Conv": Conv, "DWConv": DWConv, "Bottleneck": Bottleneck, "C2f": C2f, "C3": C3, "C3k": C3k, "C3k2": C3k2,
+            "SPPF": SPPF, "C2PSA": C2PSA, "Concat": Concat, "Detect": Detect}
+_BASE = {Conv, DWConv, Bottleneck, C2f, C3, C3k, C3k2, SPPF, C2PSA}
+_REPEAT = {C2f, C3, C3k, C3k2, C2PSA}
+
+
+def parse_model(d, ch, verbose=True):
+    """YAML dict -> (nn.Sequential, save list): the channel / depth rules of tasks.py:1085-1101, 1136-1141."""
+    legacy = True
+    max_channels = float("inf")
+    nc, act, scales = (d.get(x) for x in ("nc", "activation", "scales"))
+    depth, width = (d.get(x, 1.0) for x in ("depth_multiple", "width_multiple"))
+    scale = d.get("scale")
+    if scales:
+        if not scale:
+            scale = tuple(scales.keys())[0]
+        depth, width, max_channels = scales[scale]
+    if act:
+        Conv.default_act = eval(act)  # noqa: S307 — same contract as the reference's YAML `activation:` key
+    ch = [ch]
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
+        if isinstance(m, str) and m.startswith("nn."):
+            m = getattr(torch.nn, m[3:])
+        elif isinstance(m, str):
+            if m not in _MODULES:
+                raise ops._lib.Sy11Error(f"module '{m}' is outside the MI355X hot path (SURVEY.md §2.1): no HIP kernel")
+            m = _MODULES[m]
+        args = list(args)
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                with contextlib.suppress(ValueError):
+                    args[j] = locals()[a] if a in locals() else ast.literal_eval(a)
+        n = n_ = max(round(n * depth), 1) if n > 1 else n
+        if m in _BASE:
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if m in _REPEAT:
+                args.insert(2, n)
+                n = 1
+            if m is C3k2:
+                legacy = False
+                if scale in "mlx":
+                    args[3] = True
+        elif m is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif m is Detect:
+            args.append([ch[x] for x in f])
+            m.legacy = legacy
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
+        t = str(m)[8:-2].replace("__main__.", "")
+        m_.np = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type = i, f, t
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+def guess_model_scale(model_path):
+    try:
+        return re.search(r"yolo[v]?\d+([nslmx])", Path(model_path).stem).group(1)
+    except AttributeError:
+        return ""
+
+
+def yaml_model_load(path):
+    """'yolo11s.yaml' -> dict of cfg/models/11/yolo11.yaml with scale 's' (tasks.py:1171-1184)."""
+    path = Path(path)
+    unified = re.sub(r"(\d+)([nslmx])(.+)?$", r"\1\3", str(path.name))
+    for cand in (path, Path(unified)):
+        for base in (Path("."), CFG_DIR / "11", CFG_DIR):
+            f = base / cand
+            if f.is_file():
+                with open(f) as fh:
+                    d = yaml.safe_load(fh)
+                d["scale"] = guess_model_scale(path)
+                d["yaml_file"] = str(path)
+                return d
+    raise FileNotFoundError(f"model yaml '{path}' not found (searched {CFG_DIR})")

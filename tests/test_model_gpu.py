@@ -1,0 +1,217 @@
+"""GPU parity of the sy11 modules / DetectionModel / loss against the REFERENCE's numbers (tests/golden/*.npz)
+and against the oracle on fresh inputs.  Tolerance (north_star): logits / loss within 1e-3 in fp32;
+fp16 (the reference's AMP dtype) is checked at 2e-2 of the output scale."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import loss_ref, yolo11_ref as R
+from tests._golden import check, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def mods():
+    from sy11.nn import modules as M
+    return M
+
+
+CASES = {
+    "conv_k1": (lambda M: M.Conv(32, 64, 1, 1), (2, 32, 8, 8)),
+    "conv_k3": (lambda M: M.Conv(32, 64, 3, 1), (2, 32, 8, 8)),
+    "conv_k3s2": (lambda M: M.Conv(32, 64, 3, 2), (2, 32, 10, 10)),
+    "conv_k3s2_odd": (lambda M: M.Conv(16, 32, 3, 2), (1, 16, 9, 7)),
+    "conv_noact": (lambda M: M.Conv(32, 48, 1, 1, act=False), (2, 32, 8, 8)),
+    "conv_stem": (lambda M: M.Conv(3, 16, 3, 2), (2, 3, 16, 16)),
+    "dwconv": (lambda M: M.DWConv(64, 64, 3), (2, 64, 8, 8)),
+    "bottleneck": (lambda M: M.Bottleneck(64, 64, True, 1, (3, 3), 0.5), (2, 64, 8, 8)),
+    "c3k": (lambda M: M.C3k(64, 64, 2, True, 1), (2, 64, 8, 8)),
+    "c3k2_plain": (lambda M: M.C3k2(64, 128, 1, False, 0.25), (2, 64, 8, 8)),
+    "c3k2_c3k": (lambda M: M.C3k2(64, 64, 1, True), (2, 64, 8, 8)),
+    "sppf": (lambda M: M.SPPF(64, 64, 5), (2, 64, 8, 8)),
+    "attention": (lambda M: M.Attention(128, num_heads=2, attn_ratio=0.5), (2, 128, 6, 5)),
+    "psablock": (lambda M: M.PSABlock(128, 0.5, 2), (2, 128, 6, 5)),
+    "c2psa": (lambda M: M.C2PSA(128, 128, 1), (2, 128, 6, 5)),
+}
+
+
+def load_closed_form(m, prefix):
+    from sy11.utils.torch_utils import initialize_weights
+    initialize_weights(m)
+    sd = {k: R.closed_form(prefix + k, tuple(v.shape)) if (v.dtype.is_floating_point and "dfl." not in k) else v
+          for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_module_matches_reference_fp32(name):
+    gold = load("modules.npz")
+    ctor, shape = CASES[name]
+    m = load_closed_form(ctor(mods()), name + ".")
+    x = R.closed_form("in." + name, shape, "signed").to(DEV).requires_grad_(True)
+    m.train()
+    y = m(x)
+    g = R.closed_form("g." + name, tuple(y.shape), "signed").to(DEV)
+    (y * g).sum().backward()
+    check(gold, f"{name}.train.y", y, rtol=1e-3, atol=1e-4)
+    check(gold, f"{name}.train.dx", x.grad, rtol=2e-3, atol=2e-4)
+    for k, p in m.named_parameters():
+        check(gold, f"{name}.train.grad.{k}", p.grad, rtol=3e-3, atol=3e-4)
+    for k, b in m.named_buffers():
+        if b.dtype.is_floating_point:
+            check(gold, f"{name}.train.buf.{k}", b, rtol=1e-3, atol=1e-4)
+    m.eval()
+    with torch.no_grad():
+        check(gold, f"{name}.eval.y", m(x.detach()), rtol=1e-3, atol=1e-4)
+
+
+def test_detect_matches_reference_fp32():
+    gold = load("modules.npz")
+    M = mods()
+    det = M.Detect(nc=5, ch=(32, 64, 128))
+    det.stride = torch.tensor([8.0, 16.0, 32.0])
+    det = load_closed_form(det, "detect.")
+    feats = [R.closed_form(f"in.detect.{i}", s, "signed").to(DEV).requires_grad_(True)
+             for i, s in enumerate([(2, 32, 8, 8), (2, 64, 4, 4), (2, 128, 2, 2)])]
+    det.train()
+    maps = det(list(feats))
+    tot = 0
+    for i, mp in enumerate(maps):
+        check(gold, f"detect.train.map{i}", mp, rtol=1e-3, atol=1e-4)
+        tot = tot + (mp * R.closed_form(f"g.detect.{i}", tuple(mp.shape), "signed").to(DEV)).sum()
+    tot.backward()
+    for i, f in enumerate(feats):
+        check(gold, f"detect.train.dx{i}", f.grad, rtol=2e-3, atol=2e-4)
+    for k, p in det.named_parameters():
+        if p.requires_grad:
+            check(gold, f"detect.train.grad.{k}", p.grad, rtol=3e-3, atol=3e-4)
+    det.eval()
+    with torch.no_grad():
+        y, _ = det([f.detach() for f in feats])
+    check(gold, "detect.eval.y", y, rtol=1e-3, atol=1e-4)
+
+
+def tiny_model(nc=4, dtype=torch.float32):
+    from sy11.nn.tasks import CFG_DIR, DetectionModel
+    d = yaml.safe_load(open(CFG_DIR / "11" / "yolo11.yaml"))
+    d["scales"]["t"] = [0.5, 0.125, 1024]
+    d["scale"] = "t"
+    m = DetectionModel(d, ch=3, nc=nc, verbose=False)
+    m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    m.load_state_dict(tiny_sd())
+    m._sy11_dtype = dtype
+    return m.to(DEV)
+
+
+def tiny_sd():
+    return R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("t", nc=4)), seed=0)
+
+
+def tiny_batch(gold):
+    return {"img": R.seeded_image((2, 3, 64, 64), seed=5).to(DEV),
+            "batch_idx": torch.from_numpy(gold["batch.batch_idx"]).to(DEV),
+            "cls": torch.from_numpy(gold["batch.cls"]).to(DEV),
+            "bboxes": torch.from_numpy(gold["batch.bboxes"]).to(DEV)}
+
+
+def test_state_dict_keys_match_reference_layout():
+    m = tiny_model()
+    layers = R.resolve_graph("t", nc=4)
+    ref_keys = set(R.empty_state_dict(layers).keys())
+    assert set(m.state_dict().keys()) == ref_keys
+
+
+def test_tiny_model_train_step_matches_reference_fp32():
+    gold = load("model_t.npz")
+    m = tiny_model()
+    batch = tiny_batch(gold)
+    m.train()
+    maps = m(batch["img"])
+    for i, mp in enumerate(maps):
+        check(gold, f"train.map{i}", mp, rtol=1e-3, atol=1e-4)
+    m.load_state_dict(tiny_sd())        # same BN buffer state as the generator
+    loss, items = m(batch)
+    loss.backward()
+    assert abs(loss.item() - gold["loss"][0]) <= 1e-3 * abs(gold["loss"][0]), (loss.item(), gold["loss"][0])
+    np.testing.assert_allclose(items.double().cpu().numpy(), gold["loss_items"], rtol=1e-3)
+    names = [str(n) for n in gold["grad.names"]]
+    params = dict(m.named_parameters())
+    gmax = float(gold["grad.norm_sum"][:, 0].max())
+    for n, (gn, gs) in zip(names, gold["grad.norm_sum"]):
+        g = params[n].grad.double()
+        # some gradients are exactly zero in exact arithmetic (a BN bias feeding another train-mode BN): absolute floor
+        assert abs(g.norm().item() - gn) <= 1e-2 * gn + 1e-5 * gmax, (n, g.norm().item(), gn)
+    for k in ("model.0.conv.weight", "model.2.m.0.cv1.conv.weight", "model.10.m.0.attn.qkv.conv.weight",
+              "model.23.cv2.0.2.bias", "model.23.cv3.2.2.weight", "model.8.m.0.m.1.cv2.bn.weight"):
+        check(gold, "grad." + k, params[k].grad, rtol=5e-3, atol=1e-3)
+    sd = m.state_dict()
+    for k in ("model.0.bn.running_mean", "model.0.bn.running_var", "model.22.cv2.bn.running_var"):
+        check(gold, "buf." + k, sd[k], rtol=1e-3, atol=1e-4)
+
+
+def test_tiny_model_eval_and_fused_match_reference_fp32():
+    gold = load("model_t.npz")
+    m = tiny_model()
+    img = R.seeded_image((2, 3, 64, 64), seed=5).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        y, maps = m(img)
+        check(gold, "eval.y", y, rtol=1e-3, atol=1e-4)
+        for i, mp in enumerate(maps):
+            check(gold, f"eval.map{i}", mp, rtol=1e-3, atol=1e-4)
+        m.fuse()
+        yf, _ = m(img)
+        check(gold, "eval_fused.y", yf, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.float16, 2e-2)])
+def test_model_vs_oracle_fresh_inputs_yolo11n(dtype, tol):
+    """Full-width yolo11n at 2x3x128x128 on seeded random inputs: device forward/loss/grads vs the oracle on CPU.
+    fp32: the north-star 1e-3.  fp16 (the reference's AMP dtype; operands rounded, f32 accumulate): 2e-2."""
+    from sy11.nn.tasks import DetectionModel
+    torch.manual_seed(3)
+    m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
+    m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    sd = R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=1)
+    m.load_state_dict(sd)
+    m._sy11_dtype = dtype
+    m = m.to(DEV).train()
+    img = torch.rand(2, 3, 128, 128)
+    batch = {"img": img.to(DEV), "batch_idx": torch.tensor([0., 0., 1.]).to(DEV),
+             "cls": torch.tensor([[3.], [17.], [60.]]).to(DEV),
+             "bboxes": torch.tensor([[0.4, 0.4, 0.5, 0.4], [0.6, 0.65, 0.3, 0.5], [0.5, 0.5, 0.7, 0.6]]).to(DEV)}
+    loss, items = m(batch)
+    layers = R.resolve_graph("n", nc=80)
+    osd = {k: v.clone() for k, v in sd.items()}
+    for v in osd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    for k in osd:
+        if "running" in k:
+            osd[k] = osd[k].detach()
+    maps = R.forward(osd, layers, img, train=True)
+    oloss, oitems = loss_ref.detection_loss(maps, {k: v.cpu() for k, v in batch.items()}, nc=80)
+    assert abs(loss.item() - oloss.item()) <= tol * abs(oloss.item()), (loss.item(), oloss.item())
+    np.testing.assert_allclose(items.cpu().numpy(), oitems.numpy(), rtol=tol, atol=1e-5)
+    loss.backward()
+    oloss.backward()
+    params = dict(m.named_parameters())
+    gmax = max(osd[k].grad.norm().item() for k in params if osd[k].grad is not None)
+    # fp16: 2 images x 4x4 P5 cells -> BatchNorm over 32 samples amplifies operand rounding; per-tensor bound 25 %,
+    # median 5 %.  fp32: 1 % per tensor.
+    gtol = 1e-2 if dtype == torch.float32 else 0.25
+    bad, rels = [], []
+    for k, p in params.items():
+        if not p.requires_grad:
+            continue
+        d = (p.grad.cpu() - osd[k].grad).norm().item()
+        rels.append(d / (osd[k].grad.norm().item() + 1e-4 * gmax))
+        if d > gtol * osd[k].grad.norm().item() + 1e-4 * gmax:
+            bad.append((k, d, osd[k].grad.norm().item()))
+    assert not bad, bad[:8]
+    assert float(np.median(rels)) <= (2e-3 if dtype == torch.float32 else 5e-2), float(np.median(rels))

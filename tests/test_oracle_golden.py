@@ -95,12 +95,12 @@ def test_detect_head_matches_reference():
 
 def tiny_model():
     layers = R.resolve_graph("t", nc=4)
-    sd = R.closed_form_state_dict(R.empty_state_dict(layers))
+    sd = R.seeded_state_dict(R.empty_state_dict(layers), seed=0)
     return layers, sd
 
 
 def tiny_batch(gold):
-    return {"img": R.closed_form("in.model_t", (2, 3, 64, 64), "input"),
+    return {"img": R.seeded_image((2, 3, 64, 64), seed=5),
             "batch_idx": torch.from_numpy(gold["batch.batch_idx"]),
             "cls": torch.from_numpy(gold["batch.cls"]),
             "bboxes": torch.from_numpy(gold["batch.bboxes"])}
@@ -158,7 +158,7 @@ def test_tiny_model_train_forward_loss_grads_match_reference():
 def test_tiny_model_eval_and_fused_match_reference():
     gold = load("model_t.npz")
     layers, sd = tiny_model()
-    img = R.closed_form("in.model_t", (2, 3, 64, 64), "input")
+    img = R.seeded_image((2, 3, 64, 64), seed=5)
     with torch.no_grad():
         y, maps = R.forward(sd, layers, img, train=False)
         check(gold, "eval.y", y, rtol=2e-4, atol=2e-5)
