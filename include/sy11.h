@@ -102,7 +102,6 @@ int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, in
                           int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
                           const float* shift, const float* gamma, int32_t silu, const float* sum_g,
                           const float* sum_gx, void* dy, int32_t dy_ld, float* dgamma, float* dbeta, void* stream);
-/* SiLU backward only (fused-BN / bias epilogues): dy = dz * silu'(pre) where pre = y (pre-activation)       */
 
 /* ---- data movement inside the graph --------------------------------------------------------------------- */
 /* dst[m, 0:C] (= | +=) src[m, 0:C] with independent pixel strides: torch.cat / chunk (conv.py:1821,
@@ -120,9 +119,7 @@ int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                       void* y, int32_t y_ld, uint8_t* idx, void* stream);
 int sy11_maxpool5_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
                       const uint8_t* idx, void* dx, int32_t dx_ld, int32_t accumulate, void* stream);
-/* NCHW f32 <-> NHWC dtype boundary conversions (module-level drop-in keeps NCHW-shaped tensors)             */
-int sy11_nchw_to_nhwc(int32_t dtype, int32_t B, int32_t C, int32_t H, int32_t W, const float* x, void* y,
-                      int32_t y_ld, void* stream);
+/* flat dtype cast (f32 <-> f16 / bf16), n elements                                                          */
 int sy11_cast(int32_t src_dtype, int32_t dst_dtype, int64_t n, const void* src, void* dst, void* stream);
 
 /* ---- C2PSA attention core: softmax(q^T k * scale) applied to v (nn/modules/block.py:1925-1931) ---------- */
@@ -145,13 +142,14 @@ int sy11_nms_sorted(int32_t n, const float* boxes, float iou_thres, uint64_t* wo
 size_t sy11_nms_workspace_bytes(int32_t n);
 
 /* ---- IQ -> STFT -> power -> mel -> log producer (no reference code: README.md:7; spec in DESIGN.md) ------ */
-/* iq: (B, L) interleaved complex64; db: (B, n_mel, n_frames) f32 dB; minmax: (B,2) f32 [min,max] per image
+/* iq: (B, L) interleaved complex64; db: (B, n_frames, n_mel) f32 dB (frame-major: coalesced stores);
+ * minmax: (B,2) f32 [min,max] per image
  * (must be pre-filled with +inf/-inf by the caller or by sy11_stft_minmax_init).                            */
 int sy11_stft_logmel(int32_t B, int32_t L, int32_t n_fft, int32_t hop, int32_t n_frames, int32_t n_mel,
                      const float* iq, const float* window, const int32_t* mel_start, const float* mel_w,
                      int32_t mel_taps, float* db, float* minmax, void* stream);
 int sy11_stft_minmax_init(int32_t B, float* minmax, void* stream);
-/* img[b,c,f,t] = (db-min)/(max-min), c = 0..2, NCHW f32 (what preprocess_batch hands the model)             */
+/* img[b,c,f,t] = (db[b,t,f]-min)/(max-min), c = 0..2, NCHW f32 (what preprocess_batch hands the model)        */
 int sy11_stft_normalize(int32_t B, int32_t n_mel, int32_t n_frames, const float* db, const float* minmax,
                         float* img_nchw, void* stream);
 

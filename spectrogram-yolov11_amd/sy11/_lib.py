@@ -71,6 +71,9 @@ def load():
         raise Sy11Error(f"libsy11.so not found at {LIB_PATH}: build it with "
                         f"`make -C spectrogram-yolov11_amd/csrc` (or __graft_entry__.build()). "
                         f"There is no CPU / PyTorch fallback for the hot path.")
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's): import it FIRST so that libsy11 binds to the HIP
+    # runtime torch uses — two runtimes in one process do not share devices, streams or allocations.
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
@@ -90,5 +93,20 @@ def check(rc: int, what: str):
         raise Sy11Error(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
+# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every C-ABI call is bracketed by
+# events recorded on the CURRENT stream (the stream the kernels are launched on) and appended as
+# (name, start_event, end_event, meta).  None (default) = zero overhead.
+PROFILE = None
+PROFILE_META = None
+
+
 def call(name: str, *args):
+    if PROFILE is None:
+        check(getattr(load(), name)(*args), name)
+        return
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(getattr(load(), name)(*args), name)
+    e1.record()
+    PROFILE.append((name, e0, e1, PROFILE_META))

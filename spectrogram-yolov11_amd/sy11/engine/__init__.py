@@ -15,7 +15,7 @@ from typing import List, Optional
 
 import torch
 
-from . import ops
+from .. import ops
 
 
 class Act:

@@ -1,0 +1,103 @@
+"""Training step with the reference trainer's semantics (ultralytics/engine/trainer.py: _setup_train :230-316,
+_do_train :318-474, optimizer_step :585-593, build_optimizer :758-819), stripped to the hot path:
+AMP (fp16 operands + GradScaler), nbs=64 accumulation, 3 parameter groups, grad-clip 10, EMA, RCCL gradient sum.
+Dataset / callbacks / checkpoints / validation loops are outside the hot path (out of scope)."""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from ..utils.torch_utils import ModelEMA
+from . import ddp
+
+DEFAULTS = dict(lr0=0.01, momentum=0.937, weight_decay=0.0005, nbs=64, box=7.5, cls=0.5, dfl=1.5, amp=True,
+                optimizer="SGD", warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1)
+
+
+class DetectionTrainer:
+    """One-process-per-GPU trainer for a ``DetectionModel`` (the reference's DetectionTrainer hot path)."""
+
+    def __init__(self, model, batch_size=64, device="cuda", overrides=None, world_size=1, producer=None):
+        self.args = SimpleNamespace(**{**DEFAULTS, **(overrides or {})})
+        self.device = torch.device(device)
+        self.model = model.to(self.device)
+        self.model.args = self.args                       # v8DetectionLoss reads box / cls / dfl gains here
+        self.batch_size = batch_size
+        self.world_size = world_size
+        self.producer = producer                           # optional IQ -> image producer (SpectrogramProducer)
+        self.amp = bool(self.args.amp)
+        self.model._sy11_dtype = torch.float16 if self.amp else torch.float32
+        for k, v in self.model.named_parameters():          # trainer.py:246-252: always freeze DFL
+            if ".dfl" in k:
+                v.requires_grad = False
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp)
+        self.accumulate = max(round(self.args.nbs / (batch_size * world_size)), 1)
+        wd = self.args.weight_decay * batch_size * world_size * self.accumulate / self.args.nbs
+        self.optimizer = self.build_optimizer(self.model, self.args.optimizer, self.args.lr0, self.args.momentum, wd)
+        self.ema = ModelEMA(self.model)
+        if world_size > 1:
+            ddp.broadcast_parameters(self.model)
+            ddp.attach(self.model)
+        self.last_opt_step = -1
+        self.ni = 0
+
+    @staticmethod
+    def build_optimizer(model, name="SGD", lr=0.01, momentum=0.9, decay=1e-5):
+        """Three groups by name/type (trainer.py:776-813): biases (no decay), norm weights (no decay), the rest."""
+        g = [], [], []
+        bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
+        for module_name, module in model.named_modules():
+            for param_name, param in module.named_parameters(recurse=False):
+                if not param.requires_grad:
+                    continue
+                fullname = f"{module_name}.{param_name}" if module_name else param_name
+                if "bias" in fullname:
+                    g[2].append(param)
+                elif isinstance(module, bn):
+                    g[1].append(param)
+                else:
+                    g[0].append(param)
+        if name in {"Adam", "Adamax", "AdamW", "NAdam", "RAdam"}:
+            opt = getattr(torch.optim, name)(g[2], lr=lr, betas=(momentum, 0.999), weight_decay=0.0)
+        elif name == "SGD":
+            opt = torch.optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
+        else:
+            raise NotImplementedError(f"optimizer {name}")
+        opt.add_param_group({"params": g[0], "weight_decay": decay})
+        opt.add_param_group({"params": g[1], "weight_decay": 0.0})
+        return opt
+
+    def preprocess_batch(self, batch):
+        """detect/train.py:57-74: uint8 -> float/255; with a producer: raw IQ -> spectrogram image on device."""
+        if "iq" in batch and self.producer is not None:
+            batch["img"] = self.producer(batch["iq"].to(self.device, non_blocking=True))
+        else:
+            img = batch["img"].to(self.device, non_blocking=True)
+            batch["img"] = img.float() / 255 if img.dtype == torch.uint8 else img.float()
+        return batch
+
+    def optimizer_step(self):
+        """trainer.py:585-593."""
+        self.scaler.unscale_(self.optimizer)
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10.0)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        self.optimizer.zero_grad()
+        if self.ema:
+            self.ema.update(self.model)
+
+    def train_step(self, batch):
+        """One iteration of the hot loop (trainer.py:378-393): preprocess, forward+loss, scaled backward
+        (+ RCCL gradient sum), optimizer step every ``accumulate`` iterations."""
+        self.model.train()
+        batch = self.preprocess_batch(batch)
+        loss, items = self.model(batch)
+        self.scaler.scale(loss).backward()
+        self.ni += 1
+        if self.ni - self.last_opt_step >= self.accumulate:
+            self.optimizer_step()
+            self.last_opt_step = self.ni
+        return loss.detach(), items

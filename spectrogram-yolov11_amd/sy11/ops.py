@@ -62,6 +62,10 @@ def _desc(x_shape, x_ld, y_shape, y_ld, dtype, k, s, p, d, groups, flags):
     B, IH, IW, Cn = x_shape
     _, OH, OW, N = y_shape
     kh, kw = (k, k) if isinstance(k, int) else k
+    if _lib.PROFILE is not None:     # algorithmic FLOPs of this conv problem (same for fwd / dgrad / wgrad)
+        _lib.PROFILE_META = {"flops": 2.0 * B * OH * OW * N * (Cn // groups) * kh * kw, "groups": groups,
+                             "bytes": (B * IH * IW * Cn + B * OH * OW * N + N * (Cn // groups) * kh * kw)
+                             * torch.empty((), dtype=dtype).element_size()}
     return ConvDesc(dt_code(dtype), B, IH, IW, Cn, x_ld, OH, OW, N, y_ld, kh, kw, s, s, p, p, d, d, groups, flags)
 
 

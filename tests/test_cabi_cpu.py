@@ -1,0 +1,81 @@
+"""CPU: the C-ABI library loads, exports every symbol include/sy11.h declares, and the binding's table matches the
+header.  No compute calls (no GPU here); argument validation paths that return before any launch ARE exercised."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = (ROOT / "include" / "sy11.h").read_text()
+
+
+def declared_symbols():
+    return sorted(set(re.findall(r"\b(sy11_[a-z0-9_]+)\s*\(", HEADER)))
+
+
+def test_header_declares_expected_families():
+    syms = declared_symbols()
+    for fam in ("sy11_conv2d_fwd", "sy11_conv2d_dgrad", "sy11_conv2d_wgrad", "sy11_stem_conv_fwd", "sy11_bn_act_fwd",
+                "sy11_maxpool5_fwd", "sy11_attention_fwd", "sy11_detect_decode", "sy11_nms_sorted", "sy11_stft_logmel"):
+        assert fam in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from sy11 import _lib
+    lib = _lib.load()
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"libsy11.so does not export {s}"
+
+
+def test_binding_table_matches_header():
+    from sy11 import _lib
+    bound = set(_lib.SIGNATURES) | set(_lib.OTHER)
+    assert bound == set(declared_symbols())
+    # arity check: number of parameters in the header == number of ctypes argtypes
+    for name, args in {**_lib.SIGNATURES, **{k: v[0] for k, v in _lib.OTHER.items()}}.items():
+        m = re.search(rf"\b{name}\s*\(([^;]*?)\)\s*;", HEADER, re.S)
+        assert m, name
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(args), (name, len(params), len(args))
+
+
+def test_error_codes_and_messages_without_gpu():
+    from sy11 import _lib
+    lib = _lib.load()
+    assert lib.sy11_version() == 100
+    d = _lib.ConvDesc(dtype=7)
+    rc = lib.sy11_conv2d_fwd(C.byref(d), None, None, None, None, None, None, None)
+    assert rc == -1 and b"dtype" in lib.sy11_last_error()
+    d = _lib.ConvDesc(0, 1, 8, 8, 16, 16, 9, 9, 16, 16, 3, 3, 1, 1, 1, 1, 1, 1, 1, 0)      # OH/OW wrong (should be 8)
+    rc = lib.sy11_conv2d_fwd(C.byref(d), None, None, None, None, None, None, None)
+    assert rc == -1 and b"OH/OW" in lib.sy11_last_error()
+    rc = lib.sy11_stft_logmel(1, 100, 1000, 256, 1, 8, None, None, None, None, 8, None, None, None)
+    assert rc == -1
+    assert lib.sy11_nms_workspace_bytes(130) == 130 * 3 * 8
+    with pytest.raises(_lib.Sy11Error):
+        _lib.check(-1, "x")
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    import torch
+    from sy11 import _lib
+    from sy11.nn.modules import Conv
+    m = Conv(8, 8, 3)
+    with pytest.raises(_lib.Sy11Error):
+        m(torch.zeros(1, 8, 4, 4))
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from sy11 import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.Sy11Error):
+        _lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = ROOT / "spectrogram-yolov11_amd"
+    for f in pkg.rglob("*.py"):
+        t = f.read_text()
+        assert "import oracle" not in t and "from oracle" not in t, f
