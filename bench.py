@@ -169,6 +169,13 @@ def main():
             if meta and (name.startswith("sy11_conv2d") or name.startswith("sy11_stem")):
                 f["flops"] += meta["flops"]
                 f["bytes"] += meta["bytes"]
+        dump = os.environ.get("SY11_DUMP_LAUNCHES")
+        if dump:
+            with open(dump, "w") as fh:
+                for name, e0, e1, meta in prof:
+                    fh.write(json.dumps({"name": name, "ms": round(e0.elapsed_time(e1), 4),
+                                         "gflop": round((meta or {}).get("flops", 0) / 1e9, 3) if name.startswith(("sy11_conv2d", "sy11_stem")) else 0,
+                                         "desc": (meta or {}).get("desc") if name.startswith(("sy11_conv2d", "sy11_stem")) else None}) + "\n")
         top = max(fam.items(), key=lambda kv: kv[1]["ms"])
         name, f = top
         peak = PEAK_TFLOPS[a.dtype if name != "sy11_conv2d_wgrad" else "f32"]   # round-1 wgrad runs the f32 MFMA

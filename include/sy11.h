@@ -43,6 +43,9 @@ typedef struct sy11_conv_desc {
   int32_t KH, KW, SH, SW, PH, PW, DH, DW;
   int32_t groups;              /* 1, or == C == N (depthwise)                                  */
   uint32_t flags;              /* SY11_EPI_*                                                   */
+  int32_t stat_slots;          /* stat_sum / stat_sq are [stat_slots][N]; workgroup i adds into slot i % stat_slots
+                                  (same-address f32 atomics retire at ~25 ns each: spreading them keeps the BN
+                                  statistics off the critical path).  0 or 1 = a single [N] row.               */
 } sy11_conv_desc;
 
 int sy11_version(void);
@@ -82,9 +85,9 @@ int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw, const voi
  *      (nn/modules/conv.py:81), eps/momentum from utils/torch_utils.py:417-418, residual of Bottleneck
  *      (nn/modules/block.py:725) ------------------------------------------------------------------------- */
 
-/* from sum/sumsq over `count` pixels: mean, rstd (saved for backward), scale = gamma*rstd,
+/* from sum/sumsq (summed over stat_slots rows of C) over `count` pixels: mean, rstd (saved for backward), scale = gamma*rstd,
  * shift = beta - mean*scale, and the running-stat update (unbiased var, momentum).                          */
-int sy11_bn_finalize(int32_t C, double count, const float* stat_sum, const float* stat_sq, const float* gamma,
+int sy11_bn_finalize(int32_t C, int32_t stat_slots, double count, const float* stat_sum, const float* stat_sq, const float* gamma,
                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                      float* mean, float* rstd, float* scale, float* shift, void* stream);
 

@@ -27,6 +27,28 @@ __device__ __forceinline__ void dvstore(T* p, const float* f) {
   }
 }
 
+// the VEC channels x 9 taps a thread owns are VEC*9 CONTIGUOUS filter elements ([C][3][3] layout): 9 x 16-byte loads
+template <typename T, int VEC, int MAXT>
+__device__ __forceinline__ void load_taps(const T* __restrict__ w, int c, int Tn, float (&wr)[MAXT][VEC]) {
+  if constexpr (VEC > 1 && MAXT == 9) {
+    if (Tn == 9) {
+      T buf[VEC * 9];
+      typedef T vt __attribute__((ext_vector_type(VEC)));
+#pragma unroll
+      for (int j = 0; j < 9; ++j) *(vt*)&buf[j * VEC] = *(const vt*)(w + (long)c * 9 + j * VEC);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) wr[t][i] = ElemTraits<T>::to_f(buf[i * 9 + t]);
+      return;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) wr[t][i] = t < Tn ? ElemTraits<T>::to_f(w[(long)(c + i) * Tn + t]) : 0.f;
+}
+
 struct DwArgs {
   const void* x; const void* w; void* y; const float* bias; float* stat_sum; float* stat_sq;
   int B, IH, IW, OH, OW, C, x_ld, y_ld;
@@ -34,6 +56,7 @@ struct DwArgs {
   unsigned flags;
   int cpv, rows_pb;
   long rows_per_block;
+  int stat_slots;
 };
 
 // MAXT = taps kept in registers (9 for 3x3)
@@ -50,20 +73,16 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwArgs a) {
   for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
   if (active) {
     float wr[MAXT][VEC], bv[VEC];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) wr[t][i] = t < Tn ? ElemTraits<T>::to_f(((const T*)a.w)[(long)(c + i) * Tn + t]) : 0.f;
+    load_taps<T, VEC, MAXT>((const T*)a.w, c, Tn, wr);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) bv[i] = a.bias ? a.bias[c + i] : 0.f;
-    const long M = (long)a.B * a.OH * a.OW;
-    const long m0 = (long)blockIdx.x * a.rows_per_block;
-    const long m1 = m0 + a.rows_per_block < M ? m0 + a.rows_per_block : M;
+    const int M = a.B * a.OH * a.OW;
+    const int m0 = blockIdx.x * (int)a.rows_per_block;
+    const int m1 = m0 + (int)a.rows_per_block < M ? m0 + (int)a.rows_per_block : M;
     const bool silu = a.flags & SY11_EPI_SILU;
-    for (long m = m0 + rsub; m < m1; m += a.rows_pb) {
-      const int ox = (int)(m % a.OW);
-      const long q = m / a.OW;
-      const int oy = (int)(q % a.OH), b = (int)(q / a.OH);
+    for (int m = m0 + rsub; m < m1; m += a.rows_pb) {
+      const int q = m / a.OW, ox = m - q * a.OW;
+      const int b = q / a.OH, oy = q - b * a.OH;
       float acc[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -85,20 +104,31 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwArgs a) {
         float v = acc[i] + bv[i];
         acc[i] = silu ? silu_f(v) : v;
       }
-      dvstore<T, VEC>((T*)a.y + m * a.y_ld + c, acc);
+      dvstore<T, VEC>((T*)a.y + (long)m * a.y_ld + c, acc);
     }
   }
   if (a.stat_sum) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
     __syncthreads();
+    int half = 1;
+    while (half < a.rows_pb) half <<= 1;
+    for (half >>= 1; half >= 1; half >>= 1) {
+      if (rsub < half && rsub + half < a.rows_pb) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          red[0][threadIdx.x][i] += red[0][threadIdx.x + half * cw][i];
+          red[1][threadIdx.x][i] += red[1][threadIdx.x + half * cw][i];
+        }
+      }
+      __syncthreads();
+    }
     if (rsub == 0 && cv < a.cpv) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        float p = 0.f, q = 0.f;
-        for (int r = 0; r < a.rows_pb; ++r) { p += red[0][r * cw + cl][i]; q += red[1][r * cw + cl][i]; }
-        atomicAdd(a.stat_sum + c + i, p);
-        atomicAdd(a.stat_sq + c + i, q);
+        const long so = (long)(blockIdx.x % a.stat_slots) * a.C;
+        atomicAdd(a.stat_sum + so + c + i, red[0][threadIdx.x][i]);
+        atomicAdd(a.stat_sq + so + c + i, red[1][threadIdx.x][i]);
       }
     }
   }
@@ -113,16 +143,12 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const DwArgs a, int d
   const int c = cv * VEC;
   const int Tn = a.KH * a.KW;
   float wr[MAXT][VEC];
-#pragma unroll
-  for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) wr[t][i] = t < Tn ? ElemTraits<T>::to_f(((const T*)a.w)[(long)(c + i) * Tn + t]) : 0.f;
-  const long M = (long)a.B * a.IH * a.IW;
+  load_taps<T, VEC, MAXT>((const T*)a.w, c, Tn, wr);
+  const int M = a.B * a.IH * a.IW;
   const bool accum = a.flags & SY11_EPI_ACCUM;
-  for (long m = (long)blockIdx.x * a.rows_pb + rsub; m < M; m += (long)gridDim.x * a.rows_pb) {
-    const int ix = (int)(m % a.IW);
-    const long q = m / a.IW;
-    const int iy = (int)(q % a.IH), b = (int)(q / a.IH);
+  for (int m = blockIdx.x * a.rows_pb + rsub; m < M; m += gridDim.x * a.rows_pb) {
+    const int q = m / a.IW, ix = m - q * a.IW;
+    const int b = q / a.IH, iy = q - b * a.IH;
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -139,7 +165,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const DwArgs a, int d
         for (int i = 0; i < VEC; ++i) acc[i] += g[i] * wr[t][i];
       }
     }
-    T* dp = (T*)a.y + m * a.x_ld + c;                                                        // a.y = dx, stride x_ld
+    T* dp = (T*)a.y + (long)m * a.x_ld + c;                                                        // a.y = dx, stride x_ld
     if (accum) {
       float o[VEC];
       dvload<T, VEC>(dp, o);
@@ -153,7 +179,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const DwArgs a, int d
 // dw[c][t] += sum_m dy[m][c] * x[pix(m,t)][c]
 template <typename T, int VEC, int MAXT>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int dy_ld, float* dw) {
-  __shared__ float red[256][VEC + 1];
+  __shared__ float red[256][MAXT * VEC + 1];
   const int cw = a.cpv < 256 ? a.cpv : 256;
   const int cl = threadIdx.x % cw, cv = blockIdx.y * 256 + cl, rsub = threadIdx.x / cw;
   const bool active = cv < a.cpv && rsub < a.rows_pb;
@@ -165,15 +191,14 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int d
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
   if (active) {
-    const long M = (long)a.B * a.OH * a.OW;
-    const long m0 = (long)blockIdx.x * a.rows_per_block;
-    const long m1 = m0 + a.rows_per_block < M ? m0 + a.rows_per_block : M;
-    for (long m = m0 + rsub; m < m1; m += a.rows_pb) {
-      const int ox = (int)(m % a.OW);
-      const long q = m / a.OW;
-      const int oy = (int)(q % a.OH), b = (int)(q / a.OH);
+    const int M = a.B * a.OH * a.OW;
+    const int m0 = blockIdx.x * (int)a.rows_per_block;
+    const int m1 = m0 + (int)a.rows_per_block < M ? m0 + (int)a.rows_per_block : M;
+    for (int m = m0 + rsub; m < m1; m += a.rows_pb) {
+      const int q = m / a.OW, ox = m - q * a.OW;
+      const int b = q / a.OH, oy = q - b * a.OH;
       float g[VEC];
-      dvload<T, VEC>((const T*)a.y + m * dy_ld + c, g);                                      // a.y = dy here
+      dvload<T, VEC>((const T*)a.y + (long)m * dy_ld + c, g);                                      // a.y = dy here
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         const int r = t / a.KW, s = t - r * a.KW;
@@ -188,19 +213,25 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int d
     }
   }
 #pragma unroll
-  for (int t = 0; t < MAXT; ++t) {
-    __syncthreads();
+  for (int t = 0; t < MAXT; ++t)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) red[threadIdx.x][i] = acc[t][i];
-    __syncthreads();
-    if (t < Tn && rsub == 0 && cv < a.cpv) {
+    for (int i = 0; i < VEC; ++i) red[threadIdx.x][t * VEC + i] = acc[t][i];
+  __syncthreads();
+  int half = 1;
+  while (half < a.rows_pb) half <<= 1;
+  for (half >>= 1; half >= 1; half >>= 1) {
+    if (rsub < half && rsub + half < a.rows_pb) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float p = 0.f;
-        for (int r = 0; r < a.rows_pb; ++r) p += red[r * cw + cl][i];
-        atomicAdd(dw + (long)(c + i) * Tn + t, p);
-      }
+      for (int e = 0; e < MAXT * VEC; ++e) red[threadIdx.x][e] += red[threadIdx.x + half * cw][e];
     }
+    __syncthreads();
+  }
+  if (rsub == 0 && cv < a.cpv) {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (t < Tn) atomicAdd(dw + (long)(c + i) * Tn + t, red[threadIdx.x][t * VEC + i]);
   }
 }
 
@@ -213,11 +244,12 @@ static int dw_setup(const sy11_conv_desc* d, DwArgs& a, bool& vec, const void* p
   a.B = d->B; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.C = d->C; a.x_ld = d->x_ld; a.y_ld = d->y_ld;
   a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW; a.DH = d->DH; a.DW = d->DW;
   a.flags = d->flags;
+  a.stat_slots = d->stat_slots > 1 ? d->stat_slots : 1;
   a.cpv = d->C / v;
   const int cw = a.cpv < 256 ? a.cpv : 256;
   a.rows_pb = 256 / cw;
   long nblk = (M + (long)a.rows_pb * min_rows_per_thread - 1) / ((long)a.rows_pb * min_rows_per_thread);
-  if (nblk > 4096) nblk = 4096;
+  if (nblk > 512) nblk = 512;       // bounds the same-address stat / dw atomics per channel
   if (nblk < 1) nblk = 1;
   a.rows_per_block = ((M + nblk - 1) / nblk + a.rows_pb - 1) / a.rows_pb * a.rows_pb;
   nblk = (M + a.rows_per_block - 1) / a.rows_per_block;
@@ -232,7 +264,7 @@ int sy11_dwconv_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, 
   DwArgs a{};
   bool vec;
   dim3 grid;
-  int rc = dw_setup(d, a, vec, x, d->x_ld, y, d->y_ld, (long)d->B * d->OH * d->OW, 4, grid);
+  int rc = dw_setup(d, a, vec, x, d->x_ld, y, d->y_ld, (long)d->B * d->OH * d->OW, 16, grid);
   if (rc) return rc;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
   SY11_DISPATCH_DTYPE(d->dtype, T, {
@@ -249,7 +281,7 @@ int sy11_dwconv_dgrad_impl(const sy11_conv_desc* d, const void* dy, int dy_ld, c
   DwArgs a{};
   bool vec;
   dim3 grid;
-  int rc = dw_setup(d, a, vec, dy, dy_ld, dx, d->x_ld, (long)d->B * d->IH * d->IW, 1, grid);
+  int rc = dw_setup(d, a, vec, dy, dy_ld, dx, d->x_ld, (long)d->B * d->IH * d->IW, 16, grid);
   if (rc) return rc;
   a.x = dy; a.w = w; a.y = dx;
   SY11_DISPATCH_DTYPE(d->dtype, T, {
@@ -284,44 +316,44 @@ struct StemArgs {
   const float* x; const void* w; void* y; const float* bias; float* stat_sum; float* stat_sq;
   int B, IH, IW, OH, OW, N, y_ld, SH, SW, PH, PW;
   unsigned flags;
+  int stat_slots;
 };
 
 template <typename T, int NMAX>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
+  constexpr int ROWB = NMAX * (int)sizeof(T);       // bytes of one output pixel when N == NMAX
+  constexpr int ROWS = ROWB + 16;                   // padded LDS row (keeps 16-byte stores off one bank group)
+  constexpr int CP = ROWB / 16;                     // 16-byte chunks per pixel
   __shared__ float sw[27][NMAX];
   __shared__ float red[2][NMAX];
+  __shared__ __attribute__((aligned(16))) unsigned char stage[256 * ROWS];
   for (int i = threadIdx.x; i < 27 * NMAX; i += 256) {
     const int k = i / NMAX, n = i - k * NMAX;          // k = (r*3+s)*3 + c  (filter layout [n][r][s][c])
     sw[k][n] = n < a.N ? ElemTraits<T>::to_f(((const T*)a.w)[n * 27 + k]) : 0.f;
   }
   if (threadIdx.x < 2 * NMAX) ((float*)red)[threadIdx.x] = 0.f;
   __syncthreads();
-  const long M = (long)a.B * a.OH * a.OW;
-  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  const int M = a.B * a.OH * a.OW;
+  const int m = blockIdx.x * 256 + threadIdx.x;
   float acc[NMAX];
 #pragma unroll
   for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
   const bool ok = m < M;
   if (ok) {
-    const int ox = (int)(m % a.OW);
-    const long q = m / a.OW;
-    const int oy = (int)(q % a.OH), b = (int)(q / a.OH);
+    const int q = m / a.OW, ox = m - q * a.OW;
+    const int b = q / a.OH, oy = q - b * a.OH;
     const long plane = (long)a.IH * a.IW;
+    const float* xb = a.x + (long)b * 3 * plane;
+#pragma unroll 1
+    for (int rs = 0; rs < 9; ++rs) {                    // NOT unrolled: 9 x (3 x NMAX) FMAs keeps the filter reads transient
+      const int r = rs / 3, s_ = rs - r * 3;
+      const int iy = oy * a.SH - a.PH + r, ix = ox * a.SW - a.PW + s_;
+      const bool in = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      const long off = (long)iy * a.IW + ix;
+      const float v0 = in ? xb[off] : 0.f, v1 = in ? xb[plane + off] : 0.f, v2 = in ? xb[2 * plane + off] : 0.f;
+      const float* w0 = sw[rs * 3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int iy = oy * a.SH - a.PH + r;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int ix = ox * a.SW - a.PW + s;
-        const bool in = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float v = in ? a.x[((long)b * 3 + c) * plane + (long)iy * a.IW + ix] : 0.f;
-          const int k = (r * 3 + s) * 3 + c;
-#pragma unroll
-          for (int n = 0; n < NMAX; ++n) acc[n] += v * sw[k][n];
-        }
-      }
+      for (int n = 0; n < NMAX; ++n) acc[n] += v0 * w0[n] + v1 * w0[NMAX + n] + v2 * w0[2 * NMAX + n];
     }
   }
   const bool silu = a.flags & SY11_EPI_SILU;
@@ -334,15 +366,37 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
       if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0][n], s1); atomicAdd(&red[1][n], s2); }
     }
     __syncthreads();
-    if (threadIdx.x < a.N) { atomicAdd(a.stat_sum + threadIdx.x, red[0][threadIdx.x]); atomicAdd(a.stat_sq + threadIdx.x, red[1][threadIdx.x]); }
-  }
-  if (ok) {
-    T* yp = (T*)a.y + m * a.y_ld;
-    for (int n = 0; n < NMAX; ++n) {
-      if (n >= a.N) break;
-      float v = acc[n] + (a.bias ? a.bias[n] : 0.f);
-      yp[n] = ElemTraits<T>::from_f(silu ? silu_f(v) : v);
+    if (threadIdx.x < a.N) {
+      const long so = (long)(blockIdx.x % a.stat_slots) * a.N;
+      atomicAdd(a.stat_sum + so + threadIdx.x, red[0][threadIdx.x]);
+      atomicAdd(a.stat_sq + so + threadIdx.x, red[1][threadIdx.x]);
     }
+  }
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    const float v = acc[n] + ((a.bias && n < a.N) ? a.bias[n] : 0.f);
+    acc[n] = silu ? silu_f(v) : v;
+  }
+  if (a.N == NMAX && a.y_ld == NMAX) {
+    // the 256 pixels of this block are one contiguous run of the NHWC output: transpose through LDS so that
+    // consecutive lanes store consecutive 16-byte chunks (a thread's own pixel is 64-256 bytes apart from its neighbour's)
+    T* row = (T*)(stage + threadIdx.x * ROWS);
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) row[n] = ElemTraits<T>::from_f(acc[n]);
+    __syncthreads();
+    unsigned char* yb = (unsigned char*)a.y + (long)blockIdx.x * 256 * ROWB;
+    const int nvalid = min(256, M - blockIdx.x * 256);
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      const int id = i * 256 + threadIdx.x;
+      const int p = id / CP, cc = id - p * CP;
+      if (p < nvalid) *(uint4*)(yb + (long)id * 16) = *(const uint4*)(stage + p * ROWS + cc * 16);
+    }
+  } else if (ok) {
+    T* yp = (T*)a.y + (long)m * a.y_ld;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+      if (n < a.N) yp[n] = ElemTraits<T>::from_f(acc[n]);
   }
 }
 
@@ -419,7 +473,7 @@ extern "C" int sy11_stem_conv_fwd(const sy11_conv_desc* d, const float* x_nchw, 
   int rc = stem_check(d, "stem_conv_fwd");
   if (rc) return rc;
   SY11_REQUIRE(x_nchw && w && y && d->y_ld >= d->N, "stem_conv_fwd: bad argument");
-  StemArgs a{x_nchw, w, y, bias, stat_sum, stat_sq, d->B, d->IH, d->IW, d->OH, d->OW, d->N, d->y_ld, d->SH, d->SW, d->PH, d->PW, d->flags};
+  StemArgs a{x_nchw, w, y, bias, stat_sum, stat_sq, d->B, d->IH, d->IW, d->OH, d->OW, d->N, d->y_ld, d->SH, d->SW, d->PH, d->PW, d->flags, d->stat_slots > 1 ? d->stat_slots : 1};
   const long M = (long)d->B * d->OH * d->OW;
   dim3 grid((unsigned)((M + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -435,10 +489,10 @@ extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw
   int rc = stem_check(d, "stem_conv_wgrad");
   if (rc) return rc;
   SY11_REQUIRE(x_nchw && dy && dw && dy_ld >= d->N, "stem_conv_wgrad: bad argument");
-  StemArgs a{x_nchw, nullptr, (void*)dy, nullptr, nullptr, nullptr, d->B, d->IH, d->IW, d->OH, d->OW, d->N, 0, d->SH, d->SW, d->PH, d->PW, 0};
+  StemArgs a{x_nchw, nullptr, (void*)dy, nullptr, nullptr, nullptr, d->B, d->IH, d->IW, d->OH, d->OW, d->N, 0, d->SH, d->SW, d->PH, d->PW, 0, 1};
   const long M = (long)d->B * d->OH * d->OW;
   long nblk = (M + 1023) / 1024;
-  if (nblk > 2048) nblk = 2048;
+  if (nblk > 512) nblk = 512;
   const long ppb = ((M + nblk - 1) / nblk + 63) / 64 * 64;
   nblk = (M + ppb - 1) / ppb;
   dim3 grid((unsigned)nblk), block(256);

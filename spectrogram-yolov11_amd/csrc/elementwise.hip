@@ -56,13 +56,15 @@ static bool vec_ok(int esz, int C, std::initializer_list<int> lds, std::initiali
 }
 
 // ------------------------------------------------------------------------------------------------ BN finalize
-__global__ void bn_finalize_kernel(int C, double count, const float* __restrict__ ssum, const float* __restrict__ ssq,
+__global__ void bn_finalize_kernel(int C, int slots, double count, const float* __restrict__ ssum, const float* __restrict__ ssq,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mu = (double)ssum[c] / count;
-  double var = (double)ssq[c] / count - mu * mu;
+  double s1 = 0, s2 = 0;
+  for (int k = 0; k < slots; ++k) { s1 += (double)ssum[(long)k * C + c]; s2 += (double)ssq[(long)k * C + c]; }
+  const double mu = s1 / count;
+  double var = s2 / count - mu * mu;
   if (var < 0) var = 0;
   const float r = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = (float)mu;
@@ -77,23 +79,24 @@ __global__ void bn_finalize_kernel(int C, double count, const float* __restrict_
   }
 }
 
-extern "C" int sy11_bn_finalize(int32_t C, double count, const float* stat_sum, const float* stat_sq, const float* gamma,
+extern "C" int sy11_bn_finalize(int32_t C, int32_t stat_slots, double count, const float* stat_sum, const float* stat_sq, const float* gamma,
                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                 float* mean, float* rstd, float* scale, float* shift, void* stream) {
   SY11_REQUIRE(C > 0 && count > 0, "bn_finalize: bad C/count");
   SY11_REQUIRE(stat_sum && stat_sq && gamma && beta && mean && rstd && scale && shift, "bn_finalize: null pointer");
   SY11_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must both be given or both NULL");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, C, count, stat_sum, stat_sq, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, C, stat_slots > 1 ? stat_slots : 1, count, stat_sum, stat_sq, gamma,
                      beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
   SY11_LAUNCH_CHECK("bn_finalize");
   return SY11_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ BN apply (+SiLU, +res)
-template <typename T, int VEC>
+template <typename T, int VEC, bool SILU, bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(long M, int C, const T* __restrict__ y, int y_ld, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, int silu, const T* __restrict__ res, int res_ld,
+                                                         const float* __restrict__ shift, const T* __restrict__ res, int res_ld,
                                                          T* __restrict__ z, int z_ld, int cpv, int rows_pb) {
+  constexpr int U = 4;                                   // rows in flight per thread (memory-level parallelism)
   const int cw = cpv < 256 ? cpv : 256;
   const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
   const int rsub = threadIdx.x / cw;
@@ -102,30 +105,36 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(long M, int C, const T*
   float sc[VEC], sh[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { sc[i] = scale ? scale[c + i] : 1.f; sh[i] = shift ? shift[c + i] : 0.f; }
-  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
-    float v[VEC];
-    vload<T, VEC>(y + m * y_ld + c, v);
+  const long step = (long)gridDim.x * rows_pb;
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += step * U) {
+    float v[U][VEC], r[U][VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float t = v[i] * sc[i] + sh[i];
-      v[i] = silu ? silu_f(t) : t;
+    for (int u = 0; u < U; ++u) {
+      const long mm = m + u * step < M ? m + u * step : M - 1;     // clamped: loads stay in bounds, stores are predicated
+      vload<T, VEC>(y + mm * y_ld + c, v[u]);
+      if (RES) vload<T, VEC>(res + mm * res_ld + c, r[u]);
     }
-    if (res) {
-      float r[VEC];
-      vload<T, VEC>(res + m * res_ld + c, r);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) v[i] += r[i];
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float t = v[u][i] * sc[i] + sh[i];
+        if (SILU) t = silu_f(t);
+        if (RES) t += r[u][i];
+        v[u][i] = t;
+      }
+      if (m + u * step < M) vstore<T, VEC>(z + (m + u * step) * z_ld + c, v[u]);
     }
-    vstore<T, VEC>(z + m * z_ld + c, v);
   }
 }
 
 static inline int row_grid(long M, int rows_pb) {
-  long g = (M + rows_pb - 1) / rows_pb;
-  const long cap = 256L * 16;
+  long g = (M + rows_pb * 4L - 1) / (rows_pb * 4L);        // 4 rows per thread per trip
+  const long cap = 256L * 8;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+#define SY11_BNF(VV, SS, RR) hipLaunchKernelGGL((bn_act_fwd_kernel<T, VV, SS, RR>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, scale, shift, (const T*)res, res_ld, (T*)z, z_ld, g.cpv, g.rows_pb)
 extern "C" int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const float* scale,
                                const float* shift, int32_t silu, const void* res, int32_t res_ld, void* z, int32_t z_ld,
                                void* stream) {
@@ -138,8 +147,8 @@ extern "C" int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* 
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
-    if (v) hipLaunchKernelGGL((bn_act_fwd_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, scale, shift, silu, (const T*)res, res_ld, (T*)z, z_ld, g.cpv, g.rows_pb);
-    else hipLaunchKernelGGL((bn_act_fwd_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, scale, shift, silu, (const T*)res, res_ld, (T*)z, z_ld, g.cpv, g.rows_pb);
+    if (v) { if (silu) { if (res) SY11_BNF(VE, true, true); else SY11_BNF(VE, true, false); } else { if (res) SY11_BNF(VE, false, true); else SY11_BNF(VE, false, false); } }
+    else { if (silu) { if (res) SY11_BNF(1, true, true); else SY11_BNF(1, true, false); } else { if (res) SY11_BNF(1, false, true); else SY11_BNF(1, false, false); } }
   });
   SY11_LAUNCH_CHECK("bn_act_fwd");
   return SY11_OK;
@@ -147,11 +156,12 @@ extern "C" int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* 
 
 // ------------------------------------------------------------------------------------------------ BN backward
 // pass 1: per-channel sums of g = dz*act'(u), u = y*scale+shift, and of g*xhat, xhat = (y-mean)*rstd
-template <typename T, int VEC>
+template <typename T, int VEC, bool SILU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const T* __restrict__ y, int y_ld, const T* __restrict__ dz, int dz_ld,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ scale, const float* __restrict__ shift, int silu,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* sum_g, float* sum_gx, int cpv, int rows_pb, long rows_per_block) {
+  constexpr int U = 4;
   __shared__ float red[2][256][VEC > 1 ? VEC : 1];
   const int cw = cpv < 256 ? cpv : 256;
   const int cl = threadIdx.x % cw;
@@ -168,33 +178,53 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const
     for (int i = 0; i < VEC; ++i) { mu[i] = mean[c + i]; rs[i] = rstd[c + i]; sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
     const long m0 = (long)blockIdx.x * rows_per_block;
     const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
-    for (long m = m0 + rsub; m < m1; m += rows_pb) {
-      float vy[VEC], vg[VEC];
-      vload<T, VEC>(y + m * y_ld + c, vy);
-      vload<T, VEC>(dz + m * dz_ld + c, vg);
+    for (long m = m0 + rsub; m < m1; m += (long)rows_pb * U) {
+      float vy[U][VEC], vg[U][VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float g = vg[i];
-        if (silu) g *= dsilu_f(vy[i] * sc[i] + sh[i]);
-        sg[i] += g;
-        sgx[i] += g * (vy[i] - mu[i]) * rs[i];
+      for (int u = 0; u < U; ++u) {
+        const long mm = m + (long)u * rows_pb < m1 ? m + (long)u * rows_pb : m1 - 1;
+        vload<T, VEC>(y + mm * y_ld + c, vy[u]);
+        vload<T, VEC>(dz + mm * dz_ld + c, vg[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float live = (m + (long)u * rows_pb < m1) ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          float g = vg[u][i] * live;
+          if (SILU) g *= dsilu_f(vy[u][i] * sc[i] + sh[i]);
+          sg[i] += g;
+          sgx[i] += g * (vy[u][i] - mu[i]) * rs[i];
+        }
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { red[0][threadIdx.x][i] = sg[i]; red[1][threadIdx.x][i] = sgx[i]; }
   __syncthreads();
+  // tree reduction over the row groups (all threads take part; rows_pb need not be a power of two)
+  int half = 1;
+  while (half < rows_pb) half <<= 1;
+  for (half >>= 1; half >= 1; half >>= 1) {
+    if (rsub < half && rsub + half < rows_pb) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        red[0][threadIdx.x][i] += red[0][threadIdx.x + half * cw][i];
+        red[1][threadIdx.x][i] += red[1][threadIdx.x + half * cw][i];
+      }
+    }
+    __syncthreads();
+  }
   if (rsub == 0 && cv < cpv) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float a = 0.f, b = 0.f;
-      for (int r = 0; r < rows_pb; ++r) { a += red[0][r * cw + cl][i]; b += red[1][r * cw + cl][i]; }
-      atomicAdd(sum_g + c + i, a);
-      atomicAdd(sum_gx + c + i, b);
+      atomicAdd(sum_g + c + i, red[0][threadIdx.x][i]);
+      atomicAdd(sum_gx + c + i, red[1][threadIdx.x][i]);
     }
   }
 }
 
+#define SY11_BNR(VV, SS) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VV, SS>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, sum_g, sum_gx, g.cpv, g.rows_pb, rpb)
 extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                                       int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
                                       const float* shift, int32_t silu, float* sum_g, float* sum_gx, void* stream) {
@@ -203,8 +233,8 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {y_ld, dz_ld}, {y, dz});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
-  long nblk = (M + g.rows_pb * 16L - 1) / (g.rows_pb * 16L);   // >= 16 rows per thread
-  if (nblk > 2048) nblk = 2048;
+  long nblk = (M + g.rows_pb * 32L - 1) / (g.rows_pb * 32L);   // >= 32 rows per thread
+  if (nblk > 512) nblk = 512;      // <= 512 same-address atomics per channel (each retires in ~25 ns)
   if (nblk < 1) nblk = 1;
   const long rpb = ((M + nblk - 1) / nblk + g.rows_pb - 1) / g.rows_pb * g.rows_pb;
   nblk = (M + rpb - 1) / rpb;
@@ -212,21 +242,22 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
-    if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, silu, sum_g, sum_gx, g.cpv, g.rows_pb, rpb);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, silu, sum_g, sum_gx, g.cpv, g.rows_pb, rpb);
+    if (v) { if (silu) SY11_BNR(VE, true); else SY11_BNR(VE, false); }
+    else { if (silu) SY11_BNR(1, true); else SY11_BNR(1, false); }
   });
   SY11_LAUNCH_CHECK("bn_act_bwd_reduce");
   return SY11_OK;
 }
 
 // pass 2: dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); block (0,*) also accumulates dgamma/dbeta
-template <typename T, int VEC>
+template <typename T, int VEC, bool SILU>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const T* __restrict__ y, int y_ld, const T* __restrict__ dz, int dz_ld,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           const float* __restrict__ gamma, int silu, const float* __restrict__ sum_g,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                            const float* __restrict__ sum_gx, T* __restrict__ dy, int dy_ld, float* dgamma,
                                                            float* dbeta, int cpv, int rows_pb) {
+  constexpr int U = 4;
   const int cw = cpv < 256 ? cpv : 256;
   const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
   const int rsub = threadIdx.x / cw;
@@ -246,21 +277,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { atomicAdd(dgamma + c + i, sum_gx[c + i]); atomicAdd(dbeta + c + i, sum_g[c + i]); }
   }
-  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
-    float vy[VEC], vg[VEC];
-    vload<T, VEC>(y + m * y_ld + c, vy);
-    vload<T, VEC>(dz + m * dz_ld + c, vg);
+  const long step = (long)gridDim.x * rows_pb;
+  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += step * U) {
+    float vy[U][VEC], vg[U][VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float g = vg[i];
-      if (silu) g *= dsilu_f(vy[i] * sc[i] + sh[i]);
-      const float xhat = (vy[i] - mu[i]) * rs[i];
-      vg[i] = k0[i] * g - k1[i] - xhat * k2[i];
+    for (int u = 0; u < U; ++u) {
+      const long mm = m + u * step < M ? m + u * step : M - 1;
+      vload<T, VEC>(y + mm * y_ld + c, vy[u]);
+      vload<T, VEC>(dz + mm * dz_ld + c, vg[u]);
     }
-    vstore<T, VEC>(dy + m * dy_ld + c, vg);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float g = vg[u][i];
+        if (SILU) g *= dsilu_f(vy[u][i] * sc[i] + sh[i]);
+        const float xhat = (vy[u][i] - mu[i]) * rs[i];
+        vg[u][i] = k0[i] * g - k1[i] - xhat * k2[i];
+      }
+      if (m + u * step < M) vstore<T, VEC>(dy + (m + u * step) * dy_ld + c, vg[u]);
+    }
   }
 }
 
+#define SY11_BNA(VV, SS) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VV, SS>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb)
 extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                                      int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
                                      const float* shift, const float* gamma, int32_t silu, const float* sum_g,
@@ -275,8 +315,8 @@ extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const 
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
-    if (v) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb);
+    if (v) { if (silu) SY11_BNA(VE, true); else SY11_BNA(VE, false); }
+    else { if (silu) SY11_BNA(1, true); else SY11_BNA(1, false); }
   });
   SY11_LAUNCH_CHECK("bn_act_bwd_apply");
   return SY11_OK;
@@ -291,6 +331,7 @@ __global__ __launch_bounds__(256) void copy2d_kernel(long M, int C, const T* __r
   const int rsub = threadIdx.x / cw;
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
+#pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
     float v[VEC];
     vload<T, VEC>(src + m * src_ld + c, v);
@@ -332,6 +373,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(int B, int H, int W
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
   const long M = (long)B * H * W;
+#pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
     const int w = (int)(m % W);
     const long t = m / W;
@@ -354,6 +396,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(int B, int H, int W
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
   const long M = (long)B * H * W;
+#pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
     const int w = (int)(m % W);
     const long t = m / W;
@@ -422,6 +465,7 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(int B, int H, int W, 
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
   const long M = (long)B * H * W;
+#pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
     const int w = (int)(m % W);
     const long t = m / W;
@@ -462,6 +506,7 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(int B, int H, int W, 
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
   const long M = (long)B * H * W;
+#pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
     const int w = (int)(m % W);
     const long t = m / W;

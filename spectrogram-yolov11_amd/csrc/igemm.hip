@@ -33,6 +33,8 @@ struct IgemmArgs {
   int OHF, OWF, oy_mul, oy_add, ox_mul, ox_add;
   int dense_out;          // 1: output offset is m*y_ld (no decode)
   int tiles_n;
+  int stat_slots;
+  int vec_out;            // 1: output rows are 16-byte addressable -> LDS-transposed wide stores
   unsigned flags;
   signed char tap_dy[64];
   signed char tap_dx[64];
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 192];
   signed char* s_taps = (signed char*)(smem + 2 * STAGE);
+  __shared__ float s_red[2 * BN];                 // per-channel sum / sumsq of this tile (BN batch statistics)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of tiles
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
+  for (int i = tid; i < 2 * BN; i += 256) s_red[i] = 0.f;
   if (tid < 64) {
     s_taps[tid] = a.tap_dy[tid];
     s_taps[64 + tid] = a.tap_dx[tid];
@@ -196,12 +200,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   float ssum[NI], ssq[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) ssum[j] = ssq[j] = 0.f;
+  if (a.vec_out) {
+    // Wide-store path: the tile goes through LDS (row-major [128][BN] in the OUTPUT type, reusing the dead stage
+    // buffers) so that every lane stores 16 contiguous bytes of one pixel row instead of 64 scattered 2-byte stores.
+    const int osz = out32 ? 4 : (int)sizeof(T);
+    const int rowb = BN * osz;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = bm0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-      if (m >= a.M) continue;
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const bool rok = bm0 + rl < a.M;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int cl = wn * (BN / WN) + j * 32 + frow;
+          const int n = bn0 + cl;
+          float v = acc[i][j][e];
+          if (rok && n < a.N) { ssum[j] += v; ssq[j] += v * v; }
+          if (a.bias && n < a.N) v += a.bias[n];
+          if (silu) v = silu_f(v);
+          if (out32) *(float*)(smem + rl * rowb + cl * 4) = v;
+          else *(T*)(smem + rl * rowb + cl * (int)sizeof(T)) = ElemTraits<T>::from_f(v);
+        }
+      }
+    __syncthreads();
+    const int cpr = rowb / 16;                       // 16-byte chunks per tile row
+    const int epc_o = 16 / osz;
+    for (int idx = tid; idx < BM * cpr; idx += 256) {
+      const int rl = idx / cpr, ch = idx - rl * cpr;
+      const int m = bm0 + rl, n = bn0 + ch * epc_o;
+      if (m >= a.M || n >= a.N) continue;            // N % epc_o == 0 is guaranteed by the host for this path
       long obase;
       if (a.dense_out) {
         obase = (long)m * a.y_ld;
@@ -209,45 +237,75 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         const int b = m / ohw, r = m - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
         obase = ((long)(b * a.OHF + oy * a.oy_mul + a.oy_add) * a.OWF + ox * a.ox_mul + a.ox_add) * a.y_ld;
       }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = bn0 + wn * (BN / WN) + j * 32 + frow;
-        if (n >= a.N) continue;
-        float v = acc[i][j][e];
-        ssum[j] += v;
-        ssq[j] += v * v;
-        if (a.bias) v += a.bias[n];
-        if (silu) v = silu_f(v);
+      uint4 v = *(const uint4*)(smem + rl * rowb + ch * 16);
+      unsigned char* gp = (unsigned char*)a.y + (obase + n) * osz;
+      if (accum) {
+        const uint4 o = *(const uint4*)gp;
         if (out32) {
-          float* yp = (float*)a.y + obase + n;
-          if (accum) v += *yp;
-          *yp = v;
+          f32x4 x = __builtin_bit_cast(f32x4, v), y = __builtin_bit_cast(f32x4, o);
+          v = __builtin_bit_cast(uint4, x + y);
         } else {
-          T* yp = (T*)a.y + obase + n;
-          if (accum) v += ElemTraits<T>::to_f(*yp);
-          *yp = ElemTraits<T>::from_f(v);
+          typedef T vt8 __attribute__((ext_vector_type(16 / sizeof(T))));
+          vt8 x = __builtin_bit_cast(vt8, v), y = __builtin_bit_cast(vt8, o);
+#pragma unroll
+          for (int q = 0; q < (int)(16 / sizeof(T)); ++q) x[q] = ElemTraits<T>::from_f(ElemTraits<T>::to_f(x[q]) + ElemTraits<T>::to_f(y[q]));
+          v = __builtin_bit_cast(uint4, x);
+        }
+      }
+      *(uint4*)gp = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = bm0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (m >= a.M) continue;
+        long obase;
+        if (a.dense_out) {
+          obase = (long)m * a.y_ld;
+        } else {
+          const int b = m / ohw, r = m - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
+          obase = ((long)(b * a.OHF + oy * a.oy_mul + a.oy_add) * a.OWF + ox * a.ox_mul + a.ox_add) * a.y_ld;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = bn0 + wn * (BN / WN) + j * 32 + frow;
+          if (n >= a.N) continue;
+          float v = acc[i][j][e];
+          ssum[j] += v;
+          ssq[j] += v * v;
+          if (a.bias) v += a.bias[n];
+          if (silu) v = silu_f(v);
+          if (out32) {
+            float* yp = (float*)a.y + obase + n;
+            if (accum) v += *yp;
+            *yp = v;
+          } else {
+            T* yp = (T*)a.y + obase + n;
+            if (accum) v += ElemTraits<T>::to_f(*yp);
+            *yp = ElemTraits<T>::from_f(v);
+          }
         }
       }
     }
   }
   if (do_stats) {
-    float* red = (float*)smem;  // [2][BN]; main-loop LDS is dead after the final barrier
-    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      float s1 = ssum[j] + __shfl_xor(ssum[j], 32);
-      float s2 = ssq[j] + __shfl_xor(ssq[j], 32);
+      const float s1 = ssum[j] + __shfl_xor(ssum[j], 32);
+      const float s2 = ssq[j] + __shfl_xor(ssq[j], 32);
       if (fh == 0) {
         const int col = wn * (BN / WN) + j * 32 + frow;
-        atomicAdd(&red[col], s1);
-        atomicAdd(&red[BN + col], s2);
+        atomicAdd(&s_red[col], s1);
+        atomicAdd(&s_red[BN + col], s2);
       }
     }
     __syncthreads();
     if (tid < BN && bn0 + tid < a.N) {
-      atomicAdd(a.stat_sum + bn0 + tid, red[tid]);
-      atomicAdd(a.stat_sq + bn0 + tid, red[BN + tid]);
+      const long so = (long)(blockIdx.x % a.stat_slots) * a.N;
+      atomicAdd(a.stat_sum + so + bn0 + tid, s_red[tid]);
+      atomicAdd(a.stat_sq + so + bn0 + tid, s_red[BN + tid]);
     }
   }
 }
@@ -256,6 +314,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 template <typename T>
 static int launch_igemm(IgemmArgs& a, hipStream_t st) {
   const int tiles_m = cdiv(a.M, 128);
+  {
+    const int osz = (a.flags & SY11_EPI_OUT_F32) ? 4 : (int)sizeof(T);
+    a.vec_out = (((uintptr_t)a.y & 15) == 0) && (((long)a.y_ld * osz) % 16 == 0) && (((long)a.N * osz) % 16 == 0);
+  }
   int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   a.tiles_n = cdiv(a.N, bn);
   const long nwg = (long)tiles_m * a.tiles_n;
@@ -318,6 +380,7 @@ extern "C" int sy11_conv2d_fwd(const sy11_conv_desc* d, const void* x, const voi
   a.sy = d->SH; a.sx = d->SW;
   a.OHF = d->OH; a.OWF = d->OW; a.oy_mul = a.ox_mul = 1; a.oy_add = a.ox_add = 0; a.dense_out = 1;
   a.flags = d->flags;
+  a.stat_slots = d->stat_slots > 1 ? d->stat_slots : 1;
   for (int r = 0; r < d->KH; ++r)
     for (int s = 0; s < d->KW; ++s) {
       const int t = r * d->KW + s;
@@ -359,6 +422,7 @@ extern "C" int sy11_conv2d_dgrad(const sy11_conv_desc* d, const void* dy, int32_
       a.OHF = d->IH; a.OWF = d->IW; a.oy_mul = d->SH; a.oy_add = ph; a.ox_mul = d->SW; a.ox_add = pw;
       a.dense_out = (d->SH == 1 && d->SW == 1);
       a.flags = d->flags & SY11_EPI_ACCUM;
+      a.stat_slots = 1;
       int t = 0;
       for (int r = 0; r < d->KH; ++r) {
         const int ny = ph + d->PH - r * d->DH;

@@ -151,6 +151,154 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       }
 }
 
+
+// ------------------------------------------------------------------------------------------------ 16-bit MFMA path
+// Same GEMM, but the tiles stay f16/bf16 in LDS ([pixel][col], row stride TILE*2 + 64 bytes) and the MFMA operands —
+// 8 consecutive PIXELS of one column per lane — come from the hardware-transposing ds_read_b64_tr_b16 (two reads of
+// 4 pixels x 16 columns per 16-lane group).  The +64-byte row pad puts the 4 rows one read touches on 4 disjoint
+// 16-bank ranges (row stride = 64 mod 256 bytes): conflict-free for both 32-lane halves.  v_mfma_f32_32x32x16_{f16,bf16}.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Mma16;
+template <> struct Mma16<_Float16> {
+  static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<__bf16> {
+  static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int TILE>
+__global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
+  constexpr int BP = 64;                          // pixels per stage (4 MFMA k-steps of 16)
+  constexpr int ROWB = TILE * 2 + 64;             // LDS row stride in bytes
+  constexpr int CPR = TILE / 8;                   // 16-byte chunks per tile row
+  constexpr int RPP = 256 / CPR;                  // pixel rows per pass
+  constexpr int NPASS = BP / RPP;
+  constexpr int FI = TILE / 64;
+  constexpr int OPB = BP * ROWB;                  // bytes of one operand tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * OPB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_k = blockIdx.x % a.tiles_k, tile_n = blockIdx.x / a.tiles_k;
+  const int n0 = tile_n * TILE, k0 = tile_k * TILE;
+  const int m_begin = blockIdx.y * a.pix_per_split;
+  const int m_end = min(a.M, m_begin + a.pix_per_split);
+  if (m_begin >= m_end) return;
+
+  const int chunk = tid % CPR, prow = tid / CPR;
+  const int ncol = n0 + chunk * 8;
+  const bool n_ok = ncol < a.N;
+  const int kk = k0 + chunk * 8;
+  const bool k_ok = kk < a.K;
+  const int kt = k_ok ? kk / a.C : 0, kc = k_ok ? kk - kt * a.C : 0;
+  const int tdy = a.tap_dy[kt], tdx = a.tap_dx[kt];
+  const int ohw = a.OH * a.OW;
+  const T* __restrict__ xg = (const T*)a.x;
+  const T* __restrict__ dyg = (const T*)a.dy;
+
+  // pixel coordinates of this thread's NPASS rows, advanced incrementally (no division in the loop)
+  int pb[NPASS], py[NPASS], px[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int m = m_begin + prow + p * RPP;
+    const int mm = m < a.M ? m : 0;
+    pb[p] = mm / ohw;
+    const int r = mm - pb[p] * ohw;
+    py[p] = r / a.OW;
+    px[p] = r - py[p] * a.OW;
+  }
+  uint4 rdy[NPASS], rx[NPASS];
+  auto load_stage = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int m = m0 + prow + p * RPP;
+      const bool ok = m < m_end;
+      uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
+      if (ok && n_ok) vd = *(const uint4*)(dyg + (long)m * a.dy_ld + ncol);
+      if (ok && k_ok) {
+        const int iy = py[p] * a.sy + tdy, ix = px[p] * a.sx + tdx;
+        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
+          vx = *(const uint4*)(xg + (long)((pb[p] * a.IH + iy) * a.IW + ix) * a.x_ld + kc);
+      }
+      rdy[p] = vd; rx[p] = vx;
+      px[p] += BP;                                 // advance to the next stage's pixel
+      while (px[p] >= a.OW) { px[p] -= a.OW; ++py[p]; }
+      while (py[p] >= a.OH) { py[p] -= a.OH; ++pb[p]; }
+    }
+  };
+  auto store_stage = [&](int buf) {
+    unsigned char* sd = smem + buf * 2 * OPB;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int r = prow + p * RPP;
+      *(uint4*)(sd + r * ROWB + chunk * 16) = rdy[p];
+      *(uint4*)(sd + OPB + r * ROWB + chunk * 16) = rx[p];
+    }
+  };
+
+  f32x16 acc[FI][FI];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+  // per-lane byte offset inside an operand tile for k-step 0, first 4 rows: row = 8*(grp>>1) + q, col = 16*(grp&1) + 4*p4
+  const int lane_off = ((grp >> 1) * 8 + q) * ROWB + ((grp & 1) * 16 + p4 * 4) * 2;
+
+  const int nstage = (m_end - m_begin + BP - 1) / BP;
+  load_stage(m_begin);
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const bool more = s + 1 < nstage;
+    if (more) load_stage(m_begin + (s + 1) * BP);
+    const unsigned char* sd = smem + (s & 1) * 2 * OPB;
+#pragma unroll
+    for (int ks = 0; ks < BP / 16; ++ks) {
+      s16x8 fa[FI], fb[FI];
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        const unsigned char* pa = sd + ks * 16 * ROWB + lane_off + (wr * (TILE / 2) + i * 32) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWB));
+        fa[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < FI; ++j) {
+        const unsigned char* pbp = sd + OPB + ks * 16 * ROWB + lane_off + (wc * (TILE / 2) + j * 32) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pbp);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pbp + 4 * ROWB));
+        fb[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FI; ++j) acc[i][j] = Mma16<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) store_stage((s + 1) & 1);
+    __syncthreads();
+  }
+  const int fcol = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wr * (TILE / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int k = k0 + wc * (TILE / 2) + j * 32 + fcol;
+        if (n < a.N && k < a.K) atomicAdd(a.dw + (long)n * a.K + k, acc[i][j][e]);
+      }
+}
+
 extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, const void* dy, int dy_ld, float* dw, hipStream_t st);
 extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const void* dy, int32_t dy_ld, float* dw,
                                  void* stream) {
@@ -186,13 +334,18 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
   const int max_splits = cdiv(a.M, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  a.pix_per_split = cdiv(cdiv(a.M, splits), 32) * 32;
+  a.pix_per_split = cdiv(cdiv(a.M, splits), 64) * 64;
   splits = cdiv(a.M, a.pix_per_split);
   dim3 grid(tiles, splits), block(256);
-  if (tile == 128) {
-    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((wgrad_kernel<T, 128>), grid, block, 0, st, a));
+  if (d->dtype == SY11_F32) {
+    if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<float, 64>), grid, block, 0, st, a);
+  } else if (d->dtype == SY11_F16) {
+    if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 128>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wgrad16_kernel<_Float16, 64>), grid, block, 0, st, a);
   } else {
-    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((wgrad_kernel<T, 64>), grid, block, 0, st, a));
+    if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<__bf16, 128>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wgrad16_kernel<__bf16, 64>), grid, block, 0, st, a);
   }
   SY11_LAUNCH_CHECK("conv2d_wgrad");
   return SY11_OK;

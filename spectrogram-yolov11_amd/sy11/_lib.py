@@ -23,7 +23,7 @@ class Sy11Error(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "B", "IH", "IW", "C", "x_ld", "OH", "OW", "N", "y_ld",
-        "KH", "KW", "SH", "SW", "PH", "PW", "DH", "DW", "groups")] + [("flags", C.c_uint32)]
+        "KH", "KW", "SH", "SW", "PH", "PW", "DH", "DW", "groups")] + [("flags", C.c_uint32), ("stat_slots", C.c_int32)]
 
 
 _vp, _i32, _i64, _f32, _f64, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32
@@ -37,7 +37,7 @@ SIGNATURES = {
     "sy11_weight_transpose": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "sy11_stem_conv_fwd": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_stem_conv_wgrad": [_dp, _vp, _vp, _i32, _vp, _vp],
-    "sy11_bn_finalize": [_i32, _f64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sy11_bn_finalize": [_i32, _i32, _f64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_bn_act_fwd": [_i32, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp],
     "sy11_bn_act_bwd_reduce": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "sy11_bn_act_bwd_apply": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,

@@ -147,7 +147,8 @@ class Conv(nn.Module):
                 ops.conv2d_fwd(x.data, w, y, k, s, p, d, g)
             ops.bn_act_fwd(y, scale, shift, out.data, silu=silu, res=res.data if res is not None else None)
             return out
-        st = ec.zeros(2, N)
+        slots = 32 if B * OH * OW >= 128 * 64 else 1        # spread the per-channel stat atomics (see sy11.h)
+        st = ec.zeros(2, slots, N)
         if stem:
             ops.stem_conv_fwd(x.raw, w, y, s, p, stats=(st[0], st[1]))
         else:

@@ -58,15 +58,16 @@ def conv_out_hw(H, W, k, s, p, d=1):
     return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
 
-def _desc(x_shape, x_ld, y_shape, y_ld, dtype, k, s, p, d, groups, flags):
+def _desc(x_shape, x_ld, y_shape, y_ld, dtype, k, s, p, d, groups, flags, slots=1):
     B, IH, IW, Cn = x_shape
     _, OH, OW, N = y_shape
     kh, kw = (k, k) if isinstance(k, int) else k
     if _lib.PROFILE is not None:     # algorithmic FLOPs of this conv problem (same for fwd / dgrad / wgrad)
         _lib.PROFILE_META = {"flops": 2.0 * B * OH * OW * N * (Cn // groups) * kh * kw, "groups": groups,
                              "bytes": (B * IH * IW * Cn + B * OH * OW * N + N * (Cn // groups) * kh * kw)
-                             * torch.empty((), dtype=dtype).element_size()}
-    return ConvDesc(dt_code(dtype), B, IH, IW, Cn, x_ld, OH, OW, N, y_ld, kh, kw, s, s, p, p, d, d, groups, flags)
+                             * torch.empty((), dtype=dtype).element_size(),
+                             "desc": f"B{B} {IH}x{IW}x{Cn}->{OH}x{OW}x{N} k{kh} s{s} g{groups}"}
+    return ConvDesc(dt_code(dtype), B, IH, IW, Cn, x_ld, OH, OW, N, y_ld, kh, kw, s, s, p, p, d, d, groups, flags, slots)
 
 
 def filter_krsc(w: torch.Tensor) -> torch.Tensor:
@@ -76,10 +77,12 @@ def filter_krsc(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d_fwd(x, w_krsc, y, k, s=1, p=0, d=1, groups=1, bias=None, stats=None, silu=False, out_f32=False):
-    """x, y: NHWC views; w_krsc: contiguous [N][KH][KW][C/groups]; stats: (sum, sumsq) f32[N] accumulated into."""
+    """x, y: NHWC views; w_krsc: contiguous [N][KH][KW][C/groups]; stats: (sum, sumsq), each f32 [N] or [slots][N],
+    accumulated into."""
     _need_gpu(x, w_krsc, y, bias)
     flags = (EPI_SILU if silu else 0) | (EPI_OUT_F32 if out_f32 else 0)
-    dsc = _desc(x.shape, view_ld(x), y.shape, view_ld(y), x.dtype, k, s, p, d, groups, flags)
+    slots = stats[0].shape[0] if (stats and stats[0].dim() == 2) else 1
+    dsc = _desc(x.shape, view_ld(x), y.shape, view_ld(y), x.dtype, k, s, p, d, groups, flags, slots)
     call("sy11_conv2d_fwd", C.byref(dsc), _p(x), _p(w_krsc), _p(bias), _p(y), _p(stats[0]) if stats else None,
          _p(stats[1]) if stats else None, _stream())
     return y
@@ -115,7 +118,8 @@ def stem_conv_fwd(x_nchw, w_krsc, y, s=2, p=1, bias=None, stats=None, silu=False
     if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or x_nchw.shape[1] != 3:
         raise _lib.Sy11Error("stem_conv_fwd: x must be a contiguous NCHW f32 image with 3 channels")
     B, _, IH, IW = x_nchw.shape
-    dsc = _desc((B, IH, IW, 3), 3, y.shape, view_ld(y), y.dtype, 3, s, p, 1, 1, EPI_SILU if silu else 0)
+    slots = stats[0].shape[0] if (stats and stats[0].dim() == 2) else 1
+    dsc = _desc((B, IH, IW, 3), 3, y.shape, view_ld(y), y.dtype, 3, s, p, 1, 1, EPI_SILU if silu else 0, slots)
     call("sy11_stem_conv_fwd", C.byref(dsc), _p(x_nchw), _p(w_krsc), _p(bias), _p(y), _p(stats[0]) if stats else None,
          _p(stats[1]) if stats else None, _stream())
     return y
@@ -135,7 +139,8 @@ def _mc(t):
 
 
 def bn_finalize(count, ssum, ssq, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift):
-    call("sy11_bn_finalize", gamma.numel(), float(count), _p(ssum), _p(ssq), _p(gamma), _p(beta), eps, momentum,
+    slots = ssum.shape[0] if ssum.dim() == 2 else 1
+    call("sy11_bn_finalize", gamma.numel(), slots, float(count), _p(ssum), _p(ssq), _p(gamma), _p(beta), eps, momentum,
          _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
 
 
