@@ -96,15 +96,18 @@ int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t 
                     const float* shift, int32_t silu, const void* res, int32_t res_ld, void* z, int32_t z_ld,
                     void* stream);
 
-/* backward, pass 1: g = dz * act'(y*scale+shift);  sum_g[c] += sum g;  sum_gx[c] += sum g * xhat            */
+/* backward, pass 1: g = dz * act'(y*scale+shift);  sum_g[c] += sum g;  sum_gx[c] += sum g * xhat.
+ * sum_g / sum_gx are [sum_slots][C] (workgroup i adds into slot i % sum_slots; pass 2 folds the slots).          */
 int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                            int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
-                           const float* shift, int32_t silu, float* sum_g, float* sum_gx, void* stream);
+                           const float* shift, int32_t silu, float* sum_g, float* sum_gx, int32_t sum_slots,
+                           void* stream);
 /* backward, pass 2: dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); also dgamma += sum_gx, dbeta += sum_g     */
 int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                           int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
                           const float* shift, const float* gamma, int32_t silu, const float* sum_g,
-                          const float* sum_gx, void* dy, int32_t dy_ld, float* dgamma, float* dbeta, void* stream);
+                          const float* sum_gx, int32_t sum_slots, void* dy, int32_t dy_ld, float* dgamma, float* dbeta,
+                          void* stream);
 
 /* ---- data movement inside the graph --------------------------------------------------------------------- */
 /* dst[m, 0:C] (= | +=) src[m, 0:C] with independent pixel strides: torch.cat / chunk (conv.py:1821,

@@ -86,17 +86,21 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwArgs a) {
       float acc[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      float tv[MAXT][VEC];
+      float tm[MAXT];
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         const int r = t / a.KW, s = t - r * a.KW;
         const int iy = oy * a.SH - a.PH + r * a.DH, ix = ox * a.SW - a.PW + s * a.DW;
-        if (t < Tn && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) {
-          float v[VEC];
-          dvload<T, VEC>((const T*)a.x + ((long)(b * a.IH + iy) * a.IW + ix) * a.x_ld + c, v);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] += v[i] * wr[t][i];
-        }
+        const bool in = t < Tn && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);     // clamped: always a legal address
+        tm[t] = in ? 1.f : 0.f;
+        dvload<T, VEC>((const T*)a.x + ((long)(b * a.IH + cy) * a.IW + cx) * a.x_ld + c, tv[t]);
       }
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += tv[t][i] * (wr[t][i] * tm[t]);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         s1[i] += acc[i];
@@ -123,13 +127,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwArgs a) {
       }
       __syncthreads();
     }
-    if (rsub == 0 && cv < a.cpv) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const long so = (long)(blockIdx.x % a.stat_slots) * a.C;
-        atomicAdd(a.stat_sum + so + c + i, red[0][threadIdx.x][i]);
-        atomicAdd(a.stat_sq + so + c + i, red[1][threadIdx.x][i]);
-      }
+    const int nch = min(cw, a.cpv - (int)blockIdx.y * 256) * VEC;       // dense, consecutive-lane atomics
+    for (int e = threadIdx.x; e < nch; e += 256) {
+      const int cl2 = e / VEC, i2 = e - cl2 * VEC;
+      const long so = (long)(blockIdx.x % a.stat_slots) * a.C + blockIdx.y * 256 * VEC + e;
+      atomicAdd(a.stat_sum + so, red[0][cl2][i2]);
+      atomicAdd(a.stat_sq + so, red[1][cl2][i2]);
     }
   }
 }
@@ -152,19 +155,22 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const DwArgs a, int d
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    float tv[MAXT][VEC];
+    float tm[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       const int r = t / a.KW, s = t - r * a.KW;
       const int ny = iy + a.PH - r * a.DH, nx = ix + a.PW - s * a.DW;
       const int oy = ny / a.SH, ox = nx / a.SW;
       const bool ok = t < Tn && ny >= 0 && nx >= 0 && (ny % a.SH) == 0 && (nx % a.SW) == 0 && oy < a.OH && ox < a.OW;
-      if (ok) {
-        float g[VEC];
-        dvload<T, VEC>((const T*)a.x + ((long)(b * a.OH + oy) * a.OW + ox) * dy_ld + c, g);   // a.x = dy here
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += g[i] * wr[t][i];
-      }
+      const int cy = min(max(oy, 0), a.OH - 1), cx = min(max(ox, 0), a.OW - 1);
+      tm[t] = ok ? 1.f : 0.f;
+      dvload<T, VEC>((const T*)a.x + ((long)(b * a.OH + cy) * a.OW + cx) * dy_ld + c, tv[t]);   // a.x = dy here
     }
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += tv[t][i] * (wr[t][i] * tm[t]);
     T* dp = (T*)a.y + (long)m * a.x_ld + c;                                                        // a.y = dx, stride x_ld
     if (accum) {
       float o[VEC];
@@ -199,17 +205,21 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int d
       const int b = q / a.OH, oy = q - b * a.OH;
       float g[VEC];
       dvload<T, VEC>((const T*)a.y + (long)m * dy_ld + c, g);                                      // a.y = dy here
+      float tv[MAXT][VEC];
+      float tm[MAXT];
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         const int r = t / a.KW, s = t - r * a.KW;
         const int iy = oy * a.SH - a.PH + r * a.DH, ix = ox * a.SW - a.PW + s * a.DW;
-        if (t < Tn && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) {
-          float v[VEC];
-          dvload<T, VEC>((const T*)a.x + ((long)(b * a.IH + iy) * a.IW + ix) * a.x_ld + c, v);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[t][i] += g[i] * v[i];
-        }
+        const bool in = t < Tn && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+        tm[t] = in ? 1.f : 0.f;
+        dvload<T, VEC>((const T*)a.x + ((long)(b * a.IH + cy) * a.IW + cx) * a.x_ld + c, tv[t]);
       }
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[t][i] += (g[i] * tm[t]) * tv[t][i];
     }
   }
 #pragma unroll
@@ -226,12 +236,13 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int d
     }
     __syncthreads();
   }
-  if (rsub == 0 && cv < a.cpv) {
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i)
-        if (t < Tn) atomicAdd(dw + (long)(c + i) * Tn + t, red[threadIdx.x][t * VEC + i]);
+  {
+    const int nch = min(cw, a.cpv - (int)blockIdx.y * 256) * VEC;        // channels owned by this workgroup
+    float* base = dw + (long)blockIdx.y * 256 * VEC * Tn;
+    for (int e = threadIdx.x; e < nch * Tn; e += 256) {                  // consecutive lanes -> consecutive addresses
+      const int ch = e / Tn, t = e - ch * Tn;
+      atomicAdd(base + e, red[ch / VEC][t * VEC + (ch % VEC)]);
+    }
   }
 }
 
@@ -492,7 +503,7 @@ extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw
   StemArgs a{x_nchw, nullptr, (void*)dy, nullptr, nullptr, nullptr, d->B, d->IH, d->IW, d->OH, d->OW, d->N, 0, d->SH, d->SW, d->PH, d->PW, 0, 1};
   const long M = (long)d->B * d->OH * d->OW;
   long nblk = (M + 1023) / 1024;
-  if (nblk > 512) nblk = 512;
+  if (nblk > 2048) nblk = 2048;
   const long ppb = ((M + nblk - 1) / nblk + 63) / 64 * 64;
   nblk = (M + ppb - 1) / ppb;
   dim3 grid((unsigned)nblk), block(256);

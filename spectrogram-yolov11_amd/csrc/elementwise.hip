@@ -160,7 +160,7 @@ template <typename T, int VEC, bool SILU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const T* __restrict__ y, int y_ld, const T* __restrict__ dz, int dz_ld,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            float* sum_g, float* sum_gx, int cpv, int rows_pb, long rows_per_block) {
+                                                            float* sum_g, float* sum_gx, int cpv, int rows_pb, int slots) {
   constexpr int U = 4;
   __shared__ float red[2][256][VEC > 1 ? VEC : 1];
   const int cw = cpv < 256 ? cpv : 256;
@@ -176,19 +176,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const
     float mu[VEC], rs[VEC], sc[VEC], sh[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { mu[i] = mean[c + i]; rs[i] = rstd[c + i]; sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
-    const long m0 = (long)blockIdx.x * rows_per_block;
-    const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
-    for (long m = m0 + rsub; m < m1; m += (long)rows_pb * U) {
+    const long step = (long)gridDim.x * rows_pb;
+    for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += step * U) {
       float vy[U][VEC], vg[U][VEC];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const long mm = m + (long)u * rows_pb < m1 ? m + (long)u * rows_pb : m1 - 1;
+        const long mm = m + u * step < M ? m + u * step : M - 1;
         vload<T, VEC>(y + mm * y_ld + c, vy[u]);
         vload<T, VEC>(dz + mm * dz_ld + c, vg[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float live = (m + (long)u * rows_pb < m1) ? 1.f : 0.f;
+        const float live = (m + u * step < M) ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           float g = vg[u][i] * live;
@@ -215,29 +214,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const
     }
     __syncthreads();
   }
-  if (rsub == 0 && cv < cpv) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      atomicAdd(sum_g + c + i, red[0][threadIdx.x][i]);
-      atomicAdd(sum_gx + c + i, red[1][threadIdx.x][i]);
+  // dense atomics: lane t adds channel (blockIdx.y*256*VEC + t) -> one 256-byte request group per 64 lanes instead of
+  // VEC-strided scalars (same-line atomic REQUESTS, not bytes, are what the memory side serialises)
+  {
+    const int nch = min(cw, cpv - blockIdx.y * 256) * VEC;
+    for (int e = threadIdx.x; e < nch; e += 256) {
+      const int cl2 = e / VEC, i2 = e - cl2 * VEC;
+      const long ch = (long)(blockIdx.x % slots) * C + blockIdx.y * 256 * VEC + e;
+      atomicAdd(sum_g + ch, red[0][cl2][i2]);
+      atomicAdd(sum_gx + ch, red[1][cl2][i2]);
     }
   }
 }
 
-#define SY11_BNR(VV, SS) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VV, SS>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, sum_g, sum_gx, g.cpv, g.rows_pb, rpb)
+#define SY11_BNR(VV, SS) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VV, SS>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, sum_g, sum_gx, g.cpv, g.rows_pb, slots)
 extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                                       int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
-                                      const float* shift, int32_t silu, float* sum_g, float* sum_gx, void* stream) {
+                                      const float* shift, int32_t silu, float* sum_g, float* sum_gx, int32_t sum_slots,
+                                      void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && M > 0 && C > 0 && y && dz && mean && rstd && scale && shift && sum_g && sum_gx, "bn_act_bwd_reduce: bad argument");
   SY11_REQUIRE(y_ld >= C && dz_ld >= C, "bn_act_bwd_reduce: pixel stride < C");
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {y_ld, dz_ld}, {y, dz});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
-  long nblk = (M + g.rows_pb * 32L - 1) / (g.rows_pb * 32L);   // >= 32 rows per thread
-  if (nblk > 512) nblk = 512;      // <= 512 same-address atomics per channel (each retires in ~25 ns)
+  long nblk = (M + g.rows_pb * 8L - 1) / (g.rows_pb * 8L);     // >= 8 rows per thread
+  if (nblk > 2048) nblk = 2048;
   if (nblk < 1) nblk = 1;
-  const long rpb = ((M + nblk - 1) / nblk + g.rows_pb - 1) / g.rows_pb * g.rows_pb;
-  nblk = (M + rpb - 1) / rpb;
+  const int slots = sum_slots > 1 ? sum_slots : 1;
   dim3 grid((unsigned)nblk, g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const 
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                            const float* __restrict__ sum_gx, T* __restrict__ dy, int dy_ld, float* dgamma,
-                                                           float* dbeta, int cpv, int rows_pb) {
+                                                           float* dbeta, int cpv, int rows_pb, int slots) {
   constexpr int U = 4;
   const int cw = cpv < 256 ? cpv : 256;
   const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
@@ -265,17 +268,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const 
   const int c = cv * VEC;
   const float invM = 1.0f / (float)M;
   float mu[VEC], rs[VEC], sc[VEC], sh[VEC], k0[VEC], k1[VEC], k2[VEC];
+  // fold the (<= 8) partial-sum slots: all loads issued up front (clamped slot index + 0/1 weight), no dependent chain
+  constexpr int MAXS = 8;
+  float pg[MAXS][VEC], pgx[MAXS][VEC];
+#pragma unroll
+  for (int k = 0; k < MAXS; ++k) {
+    const int kk = k < slots ? k : 0;
+    vload<float, VEC>(sum_g + (long)kk * C + c, pg[k]);
+    vload<float, VEC>(sum_gx + (long)kk * C + c, pgx[k]);
+  }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     mu[i] = mean[c + i]; rs[i] = rstd[c + i]; sc[i] = scale[c + i]; sh[i] = shift[c + i];
+    float tg = 0.f, tgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+      const float wk = k < slots ? 1.f : 0.f;
+      tg += pg[k][i] * wk;
+      tgx += pgx[k][i] * wk;
+    }
     const float gr = gamma[c + i] * rs[i];
     k0[i] = gr;
-    k1[i] = gr * sum_g[c + i] * invM;
-    k2[i] = gr * sum_gx[c + i] * invM;
-  }
-  if (blockIdx.x == 0 && rsub == 0 && dgamma) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { atomicAdd(dgamma + c + i, sum_gx[c + i]); atomicAdd(dbeta + c + i, sum_g[c + i]); }
+    k1[i] = gr * tg * invM;
+    k2[i] = gr * tgx * invM;
+    if (blockIdx.x == 0 && rsub == 0 && dgamma) { atomicAdd(dgamma + c + i, tgx); atomicAdd(dbeta + c + i, tg); }
   }
   const long step = (long)gridDim.x * rows_pb;
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += step * U) {
@@ -300,13 +316,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const 
   }
 }
 
-#define SY11_BNA(VV, SS) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VV, SS>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb)
+#define SY11_BNA(VV, SS) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VV, SS>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb, sum_slots > 1 ? sum_slots : 1)
 extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                                      int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
                                      const float* shift, const float* gamma, int32_t silu, const float* sum_g,
-                                     const float* sum_gx, void* dy, int32_t dy_ld, float* dgamma, float* dbeta, void* stream) {
+                                     const float* sum_gx, int32_t sum_slots, void* dy, int32_t dy_ld, float* dgamma, float* dbeta,
+                                     void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && M > 0 && C > 0 && y && dz && dy && mean && rstd && scale && shift && gamma && sum_g && sum_gx, "bn_act_bwd_apply: bad argument");
   SY11_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_act_bwd_apply: dgamma/dbeta both or neither");
+  SY11_REQUIRE(sum_slots <= 8, "bn_act_bwd_apply: at most 8 partial-sum slots");
   SY11_REQUIRE(y_ld >= C && dz_ld >= C && dy_ld >= C, "bn_act_bwd_apply: pixel stride < C");
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {y_ld, dz_ld, dy_ld}, {y, dz, dy});

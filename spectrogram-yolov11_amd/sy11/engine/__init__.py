@@ -95,18 +95,33 @@ class Act:
 class Ctx:
     """State of one forward pass through the engine."""
 
-    def __init__(self, training: bool, record: bool, dtype: torch.dtype, device, grads: Optional["GradStore"]):
+    def __init__(self, training: bool, record: bool, dtype: torch.dtype, device, grads: Optional["GradStore"],
+                 pool_hint: int = 0):
         self.training = training
         self.record = record          # build a backward tape
         self.dtype = dtype
         self.device = device
         self.tape: List = []
         self.grads = grads
+        # one memset for all the small f32 accumulators (BN statistics, backward sums) of a step instead of ~160 fills
+        self.pool = torch.zeros(pool_hint, dtype=torch.float32, device=device) if pool_hint > 0 else None
+        self.pool_off = 0
+        self.pool_need = 0
+        self.bn_counters: List[torch.Tensor] = []
 
     def empty(self, B, H, W, Cn, dtype=None):
         return torch.empty((B, H, W, Cn), dtype=dtype or self.dtype, device=self.device)
 
     def zeros(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n4 = (n + 3) // 4 * 4                       # keep every carve 16-byte aligned
+        self.pool_need += n4
+        if self.pool is not None and self.pool_off + n4 <= self.pool.numel():
+            t = self.pool[self.pool_off:self.pool_off + n].view(shape)
+            self.pool_off += n4
+            return t
         return torch.zeros(shape, dtype=torch.float32, device=self.device)
 
 
@@ -196,9 +211,12 @@ class EngineFn(torch.autograd.Function):
             if store is None:
                 store = GradStore(module)
                 module.__dict__["_sy11_grads"] = store
-        ec = Ctx(module.training, record, dtype, ins[0].device, store)
+        ec = Ctx(module.training, record, dtype, ins[0].device, store, module.__dict__.get("_sy11_pool_hint", 0))
         acts = [to_act(t, dtype) for t in ins]
         out = module._run(ec, acts if is_list else acts[0])
+        if ec.bn_counters:
+            torch._foreach_add_(ec.bn_counters, 1)          # num_batches_tracked of every BN in one multi-tensor launch
+        ctx.module = module
         outs, out_list = _flatten(out)
         ctx.ec, ctx.acts, ctx.outs, ctx.n_in = ec, acts, outs, n_in
         ctx.n_t = len(tensors)
@@ -220,6 +238,7 @@ class EngineFn(torch.autograd.Function):
         for bw in reversed(ec.tape):
             bw()
         ec.tape.clear()
+        ctx.module.__dict__["_sy11_pool_hint"] = ec.pool_need       # next step: one pooled allocation
         gin = []
         for a, req in zip(ctx.acts, ctx.in_req):
             if req:

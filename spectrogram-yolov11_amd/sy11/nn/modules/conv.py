@@ -161,13 +161,13 @@ class Conv(nn.Module):
         ops.bn_finalize(B * OH * OW, st[0], st[1], gamma, beta, bn.eps, mom, bn.running_mean if track else None,
                         bn.running_var if track else None, mean, rstd, scale, shift)
         if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            ec.bn_counters.append(bn.num_batches_tracked)
         ops.bn_act_fwd(y, scale, shift, out.data, silu=silu, res=res.data if res is not None else None)
         if ec.record:
             def bw():
                 gs = ec.grads
                 dz = out.grad_read()
-                sg = ec.zeros(2, N)
+                sg = ec.zeros(2, 8 if B * OH * OW >= 8192 else 1, N)     # 8 slots: spread the same-line atomics
                 ops.bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, silu, sg[0], sg[1])
                 dy = torch.empty_like(y)
                 has_bn = id(bn.weight) in gs.views

@@ -154,15 +154,17 @@ def bn_act_fwd(y, scale, shift, z, silu=True, res=None):
 
 def bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, silu, sum_g, sum_gx):
     M, Cn = _mc(y)
+    slots = sum_g.shape[0] if sum_g.dim() == 2 else 1
     call("sy11_bn_act_bwd_reduce", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
-         _p(scale), _p(shift), int(silu), _p(sum_g), _p(sum_gx), _stream())
+         _p(scale), _p(shift), int(silu), _p(sum_g), _p(sum_gx), slots, _stream())
 
 
 def bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, dy, dgamma, dbeta):
     M, Cn = _mc(y)
+    slots = sum_g.shape[0] if sum_g.dim() == 2 else 1
     call("sy11_bn_act_bwd_apply", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
-         _p(scale), _p(shift), _p(gamma), int(silu), _p(sum_g), _p(sum_gx), _p(dy), view_ld(dy), _p(dgamma), _p(dbeta),
-         _stream())
+         _p(scale), _p(shift), _p(gamma), int(silu), _p(sum_g), _p(sum_gx), slots, _p(dy), view_ld(dy), _p(dgamma),
+         _p(dbeta), _stream())
 
 
 def copy2d(src, dst, accumulate=False):

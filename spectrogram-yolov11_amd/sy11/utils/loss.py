@@ -83,7 +83,8 @@ class v8DetectionLoss:
     def bbox_decode(self, anchor_points, pred_dist):
         if self.use_dfl:
             b, a, c = pred_dist.shape
-            pred_dist = pred_dist.view(b, a, 4, c // 4).softmax(3).matmul(self.proj.type(pred_dist.dtype))
+            # (softmax * proj).sum == softmax @ proj; the elementwise form avoids a (B*A*4, 16) x 16 rocBLAS gemv (1.4 ms)
+            pred_dist = (pred_dist.view(b, a, 4, c // 4).softmax(3) * self.proj.type(pred_dist.dtype)).sum(3)
         return dist2bbox(pred_dist, anchor_points, xywh=False)
 
     def __call__(self, preds, batch):
