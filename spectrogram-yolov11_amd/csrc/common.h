@@ -54,10 +54,10 @@ template <> struct ElemTraits<__bf16> {
   static __device__ __forceinline__ __bf16 from_f(float x) { return (__bf16)x; }
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }   // 1-ulp rcp
 // d/dv silu(v) = s + v*s*(1-s),  s = sigmoid(v)
 __device__ __forceinline__ float dsilu_f(float v) {
-  float s = 1.0f / (1.0f + __expf(-v));
+  float s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
   return s * (1.0f + v * (1.0f - s));
 }
 

@@ -17,6 +17,10 @@
 // The same kernel computes the data gradient: input := dy, filter := tap-transposed weights, taps := the
 // (P - r*D)/S offsets of one output-parity class, output written with a pixel stride (oy*oy_mul+oy_add).
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+__device__ uint4 g_zero16;   // zero page: source of padded / out-of-range 16-byte chunks (zero-initialised)
 
 struct IgemmArgs {
   const void* x;
@@ -34,6 +38,7 @@ struct IgemmArgs {
   int dense_out;          // 1: output offset is m*y_ld (no decode)
   int tiles_n;
   int stat_slots;
+  unsigned x_bytes, w_bytes;   // extents of the x / w views in bytes (buffer descriptors range-check against them)
   int vec_out;            // 1: output rows are 16-byte addressable -> LDS-transposed wide stores
   unsigned flags;
   signed char tap_dy[64];
@@ -61,17 +66,25 @@ template <> struct Mma<__bf16> {
   }
 };
 
-template <typename T, int BN, int WM, int WN>
+// KB = bytes of K per LDS row / stage (128 or 64), NST = LDS ring depth (2 or 3).
+template <int KB> __device__ __forceinline__ int swz(int r) { return KB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+
+// EPI: compile-time epilogue (bit 0 stats, 1 bias, 2 SiLU, 3 accumulate, 4 f32 output) or -1 = decide from runtime flags.
+// Small-K layers (1x1 convs, K = 64..192) spend most of their instructions in the epilogue, so its dead branches matter.
+template <typename T, int BN, int WM, int WN, int KB, int NST, int EPI>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   constexpr int BM = 128;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
-  constexpr int BK = 8 * EPC;               // elements per 128-byte LDS row
+  constexpr int CPRW = KB / 16;             // 16-byte chunks per LDS row
+  constexpr int BK = CPRW * EPC;            // elements of K per stage
+  constexpr int RPI = 64 / CPRW;            // tile rows moved by one wave-wide LDS-DMA instruction (1 KiB)
+  constexpr int RPP = 4 * RPI;              // rows per pass of the 4 waves
   constexpr int MI = BM / WM / 32;
   constexpr int NI = BN / WN / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB, STAGE = A_BYTES + B_BYTES;
   static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 192];
-  signed char* s_taps = (signed char*)(smem + 2 * STAGE);
+  static_assert(BN % RPP == 0 || BN < RPP, "pass geometry");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE + 192 + 512];
   __shared__ float s_red[2 * BN];                 // per-channel sum / sumsq of this tile (BN batch statistics)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,68 +99,83 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
   for (int i = tid; i < 2 * BN; i += 256) s_red[i] = 0.f;
-  if (tid < 64) {
-    s_taps[tid] = a.tap_dy[tid];
-    s_taps[64 + tid] = a.tap_dx[tid];
-    s_taps[128 + tid] = a.tap_w[tid];
-  }
 
-  // ---- staging roles: 8 consecutive lanes cover one 128-byte row; rows ld_row + 32*i
-  const int ld_chunk = tid & 7, ld_row = tid >> 3;
-  int a_pix[BM / 32], a_iy[BM / 32], a_ix[BM / 32];
+  constexpr int APASS = BM / RPP, BPASS = (BN + RPP - 1) / RPP;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr unsigned OOB = 0x80000000u;      // any offset >= num_records makes the buffer load return zeros (padding / tails)
+  // ---- staging by LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): 64 lanes x 16 bytes land at
+  // (wave-uniform LDS base + lane*16) = RPI consecutive tile rows; no VGPR round trip, no ds_write.  The bank swizzle sits
+  // on the SOURCE side (the lane landing on physical chunk p of row r fetches logical chunk p ^ swz(r)).  All per-stage
+  // address work is hoisted: a row's byte offset at tap (0,0) and a 64-bit "tap is inside the image" mask are computed
+  // once; a stage adds one per-tap delta (LDS table) and turns invalid lanes into an out-of-range offset (hardware zero fill).
+  const int ld_row = tid / CPRW;
+  const int ld_chunk = (tid % CPRW) ^ swz<KB>(ld_row);           // LOGICAL chunk this lane fetches (swizzle is pass-invariant)
+  int* s_tapoff = (int*)(smem + NST * STAGE + 192);              // [64] byte delta of tap t in x, [64] byte delta in w
+  if (tid < 64) {
+    const int t = tid < a.T ? tid : 0;
+    s_tapoff[tid] = (a.tap_dy[t] * a.IW + a.tap_dx[t]) * a.x_ld * ESZ;
+    s_tapoff[64 + tid] = a.tap_w[t] * a.C * ESZ;
+  }
   const int ohw = a.OH * a.OW;
+  int a_off[APASS];
+  unsigned long long a_mask[APASS];
 #pragma unroll
-  for (int i = 0; i < BM / 32; ++i) {
-    const int m = bm0 + ld_row + 32 * i;
+  for (int i = 0; i < APASS; ++i) {
+    const int m = bm0 + ld_row + RPP * i;
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
     const int b = mm / ohw, r = mm - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
-    a_pix[i] = b * a.IH * a.IW;
-    a_iy[i] = ok ? oy * a.sy : -(1 << 20);
-    a_ix[i] = ox * a.sx;
+    const int iy0 = oy * a.sy, ix0 = ox * a.sx;
+    a_off[i] = ((b * a.IH + iy0) * a.IW + ix0) * a.x_ld * ESZ;       // host guarantees < 2^31 bytes
+    unsigned long long mk = 0;
+    if (ok)
+#pragma unroll 1
+      for (int t = 0; t < a.T; ++t) {
+        const int iy = iy0 + a.tap_dy[t], ix = ix0 + a.tap_dx[t];
+        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) mk |= 1ull << t;
+      }
+    a_mask[i] = mk;
+  }
+  int b_off[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const int rl = ld_row + RPP * i, n = bn0 + rl;
+    b_off[i] = (n < a.N && rl < BN) ? n * a.wK * ESZ : (int)OOB;
   }
   int kt = (ld_chunk * EPC) / a.C;             // tap of this thread's chunk in the current stage
   int kc = (ld_chunk * EPC) - kt * a.C;        // channel within the tap
-  const T* __restrict__ xg = (const T*)a.x;
-  const T* __restrict__ wg = (const T*)a.w;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  const bool simple_k = a.C >= BK;
+  const bool b_issue = (BN >= RPP) || (wave * RPI < BN);           // BN < rows-per-pass: only waves covering real rows issue
+  __syncthreads();  // tap tables visible
 
-  uint4 ra[BM / 32], rb[BN / 32];
-  __syncthreads();  // taps visible
-
-  auto load_stage = [&]() {
+  auto issue_stage = [&](unsigned char* stage_base) {
+    unsigned char* sa = stage_base + wave * (RPI * KB);
+    unsigned char* sb = sa + A_BYTES;
     const bool kvalid = kt < a.T;
     const int tt = kvalid ? kt : 0;
-    const int dy = s_taps[tt], dx = s_taps[64 + tt], tw = s_taps[128 + tt];
+    const int xo = s_tapoff[tt] + kc * ESZ, wo = s_tapoff[64 + tt] + kc * ESZ;
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-      const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-      const bool ok = kvalid && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *(const uint4*)(xg + (long)(a_pix[i] + iy * a.IW + ix) * a.x_ld + kc);
-      ra[i] = v;
+    for (int i = 0; i < APASS; ++i) {
+      const bool ok = kvalid && ((a_mask[i] >> tt) & 1ull);
+      const unsigned off = ok ? (unsigned)(a_off[i] + xo) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(sa + i * (RPP * KB)), 16, off, 0, 0, 0);
     }
+    if (b_issue) {
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
-      const int n = bn0 + ld_row + 32 * i;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kvalid && n < a.N) v = *(const uint4*)(wg + (long)n * a.wK + tw * a.C + kc);
-      rb[i] = v;
+      for (int i = 0; i < BPASS; ++i) {
+        const unsigned off = (kvalid && b_off[i] >= 0) ? (unsigned)(b_off[i] + wo) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_, (__attribute__((address_space(3))) void*)(sb + i * (RPP * KB)), 16, off, 0, 0, 0);
+      }
     }
     kc += BK;
-    while (kc >= a.C) { kc -= a.C; ++kt; }
-  };
-  auto store_stage = [&](int buf) {
-    unsigned char* sa = smem + buf * STAGE;
-    unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-      const int r = ld_row + 32 * i;
-      *(uint4*)(sa + r * 128 + ((ld_chunk ^ ((r >> 1) & 7)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
-      const int r = ld_row + 32 * i;
-      *(uint4*)(sb + r * 128 + ((ld_chunk ^ ((r >> 1) & 7)) << 4)) = rb[i];
+    if (simple_k) {                               // C >= BK: at most one tap boundary per stage, branch-free
+      const bool wrap = kc >= a.C;
+      kc -= wrap ? a.C : 0;
+      kt += wrap ? 1 : 0;
+    } else {
+      while (kc >= a.C) { kc -= a.C; ++kt; }
     }
   };
 
@@ -162,45 +190,71 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 31, fh = lane >> 5;
   const int nstage = (a.K + BK - 1) / BK;
+  // fragment read addresses (bytes inside a stage), hoisted: one per (tile row set, k-group)
+  int fa_off[MI][CPRW / 2], fb_off[NI][CPRW / 2];
+#pragma unroll
+  for (int g = 0; g < CPRW / 2; ++g) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int r = wm * (BM / WM) + i * 32 + frow;
+      fa_off[i][g] = r * KB + (((2 * g + fh) ^ swz<KB>(r)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int r = wn * (BN / WN) + j * 32 + frow;
+      fb_off[j][g] = A_BYTES + r * KB + (((2 * g + fh) ^ swz<KB>(r)) << 4);
+    }
+  }
 
-  load_stage();
-  store_stage(0);
-  __syncthreads();
-  for (int s = 0; s < nstage; ++s) {
-    const bool more = s + 1 < nstage;
-    if (more) load_stage();
-    const unsigned char* sa = smem + (s & 1) * STAGE;
-    const unsigned char* sb = sa + A_BYTES;
+  // NST-deep LDS ring, ONE raw barrier per stage, counted vmcnt; the ring walk is unrolled NST times so every LDS
+  // address is (hoisted VGPR + compile-time stage offset).
+  auto consume = [&](const unsigned char* st) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < CPRW / 2; ++g) {
       uint4 fa[MI], fb[NI];
-      const int ch = 2 * g + fh;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int r = wm * (BM / WM) + i * 32 + frow;
-        fa[i] = *(const uint4*)(sa + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
-      }
+      for (int i = 0; i < MI; ++i) fa[i] = *(const uint4*)(st + fa_off[i][g]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int r = wn * (BN / WN) + j * 32 + frow;
-        fb[j] = *(const uint4*)(sb + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
-      }
+      for (int j = 0; j < NI; ++j) fb[j] = *(const uint4*)(st + fb_off[j][g]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
     }
-    if (more) store_stage((s + 1) & 1);
-    __syncthreads();
+  };
+  issue_stage(smem);
+  if (NST == 3 && nstage > 1) issue_stage(smem + STAGE);
+  for (int s0 = 0; s0 < nstage; s0 += NST) {
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int s = s0 + u;
+      if (s < nstage) {
+        if (NST == 3 && s + 1 < nstage) {
+          if (b_issue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS + BPASS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s + NST - 1 < nstage) issue_stage(smem + ((u + NST - 1) % NST) * STAGE);
+        consume(smem + u * STAGE);
+      }
+    }
   }
+  __syncthreads();                               // all fragment reads done before the epilogue reuses the ring
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const bool do_stats = a.stat_sum != nullptr;
-  const bool silu = a.flags & SY11_EPI_SILU, accum = a.flags & SY11_EPI_ACCUM, out32 = a.flags & SY11_EPI_OUT_F32;
+  constexpr bool RT = EPI < 0;
+  const bool do_stats = RT ? (a.stat_sum != nullptr) : bool(EPI & 1);
+  const bool has_bias = RT ? (a.bias != nullptr) : bool(EPI & 2);
+  const bool silu = RT ? bool(a.flags & SY11_EPI_SILU) : bool(EPI & 4);
+  const bool accum = RT ? bool(a.flags & SY11_EPI_ACCUM) : bool(EPI & 8);
+  const bool out32 = RT ? bool(a.flags & SY11_EPI_OUT_F32) : bool(EPI & 16);
   float ssum[NI], ssq[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) ssum[j] = ssq[j] = 0.f;
-  if (a.vec_out) {
+  if (a.vec_out && BM * BN * ((a.flags & SY11_EPI_OUT_F32) ? 4 : (int)sizeof(T)) <= NST * STAGE) {
     // Wide-store path: the tile goes through LDS (row-major [128][BN] in the OUTPUT type, reusing the dead stage
     // buffers) so that every lane stores 16 contiguous bytes of one pixel row instead of 64 scattered 2-byte stores.
     const int osz = out32 ? 4 : (int)sizeof(T);
@@ -216,8 +270,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
           const int cl = wn * (BN / WN) + j * 32 + frow;
           const int n = bn0 + cl;
           float v = acc[i][j][e];
-          if (rok && n < a.N) { ssum[j] += v; ssq[j] += v * v; }
-          if (a.bias && n < a.N) v += a.bias[n];
+          if (do_stats && rok && n < a.N) { ssum[j] += v; ssq[j] += v * v; }
+          if (has_bias && n < a.N) v += a.bias[n];
           if (silu) v = silu_f(v);
           if (out32) *(float*)(smem + rl * rowb + cl * 4) = v;
           else *(T*)(smem + rl * rowb + cl * (int)sizeof(T)) = ElemTraits<T>::from_f(v);
@@ -273,9 +327,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
           const int n = bn0 + wn * (BN / WN) + j * 32 + frow;
           if (n >= a.N) continue;
           float v = acc[i][j][e];
-          ssum[j] += v;
-          ssq[j] += v * v;
-          if (a.bias) v += a.bias[n];
+          if (do_stats) { ssum[j] += v; ssq[j] += v * v; }
+          if (has_bias) v += a.bias[n];
           if (silu) v = silu_f(v);
           if (out32) {
             float* yp = (float*)a.y + obase + n;
@@ -315,6 +368,14 @@ template <typename T>
 static int launch_igemm(IgemmArgs& a, hipStream_t st) {
   const int tiles_m = cdiv(a.M, 128);
   {
+    const long esz = (long)sizeof(T);
+    const long rows_in = (long)(a.M / (a.OH * a.OW)) * a.IH * a.IW;
+    const long xb = ((rows_in - 1) * a.x_ld + a.C) * esz, wb = (long)a.N * a.wK * esz;
+    if (xb >= (1L << 31) || wb >= (1L << 31)) SY11_FAIL(SY11_EUNSUPPORTED, "igemm: operand view larger than 2 GiB (%ld / %ld bytes)", xb, wb);
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
+  }
+  {
     const int osz = (a.flags & SY11_EPI_OUT_F32) ? 4 : (int)sizeof(T);
     a.vec_out = (((uintptr_t)a.y & 15) == 0) && (((long)a.y_ld * osz) % 16 == 0) && (((long)a.N * osz) % 16 == 0);
   }
@@ -323,9 +384,34 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
   const long nwg = (long)tiles_m * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg), block(256);
-  if (bn == 128) hipLaunchKernelGGL((igemm_kernel<T, 128, 2, 2>), grid, block, 0, st, a);
-  else if (bn == 64) hipLaunchKernelGGL((igemm_kernel<T, 64, 4, 1>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((igemm_kernel<T, 32, 4, 1>), grid, block, 0, st, a);
+  static int variant = -1;                       // SY11_IGEMM_VARIANT: 0 = 128-byte stages x2 (2 WG/CU), 1 = 64-byte stages x2 (4 WG/CU)
+  if (variant < 0) { const char* e = getenv("SY11_IGEMM_VARIANT"); variant = e ? atoi(e) : 1; }
+  // epilogue specialisation: the common flag sets get branch-free code, anything else the runtime-flag build (EPI = -1)
+  int epi = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
+            ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
+  if (sizeof(T) == 2 && !std::is_same<T, _Float16>::value) epi = -1;          // bf16: generic build only
+#define SY11_IGV(BNN, WMM, WNN, EE)                                                                                  \
+  do {                                                                                                               \
+    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, BNN, WMM, WNN, 128, 2, EE>), grid, block, 0, st, a);       \
+    else hipLaunchKernelGGL((igemm_kernel<T, BNN, WMM, WNN, 64, 2, EE>), grid, block, 0, st, a);                     \
+  } while (0)
+#define SY11_IG(BNN, WMM, WNN)                                   \
+  do {                                                           \
+    switch (epi) {                                               \
+      case 0: SY11_IGV(BNN, WMM, WNN, 0); break;                 \
+      case 1: SY11_IGV(BNN, WMM, WNN, 1); break;                 \
+      case 8: SY11_IGV(BNN, WMM, WNN, 8); break;                 \
+      case 2: SY11_IGV(BNN, WMM, WNN, 2); break;                 \
+      case 6: SY11_IGV(BNN, WMM, WNN, 6); break;                 \
+      case 18: SY11_IGV(BNN, WMM, WNN, 18); break;               \
+      default: SY11_IGV(BNN, WMM, WNN, -1); break;               \
+    }                                                            \
+  } while (0)
+  if (bn == 128) SY11_IG(128, 2, 2);
+  else if (bn == 64) SY11_IG(64, 4, 1);
+  else SY11_IG(32, 4, 1);
+#undef SY11_IGV
+#undef SY11_IG
   SY11_LAUNCH_CHECK("igemm");
   return SY11_OK;
 }
