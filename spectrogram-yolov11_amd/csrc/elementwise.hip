@@ -56,13 +56,23 @@ static bool vec_ok(int esz, int C, std::initializer_list<int> lds, std::initiali
 }
 
 // ------------------------------------------------------------------------------------------------ BN finalize
-__global__ void bn_finalize_kernel(int C, int slots, double count, const float* __restrict__ ssum, const float* __restrict__ ssq,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-                                   float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int C, int slots, double count, const float* __restrict__ ssum,
+                                                          const float* __restrict__ ssq, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                                          float* running_var, float* mean, float* rstd, float* scale, float* shift) {
+  // 32 channels per block; 8 lanes-groups split the slots of a channel, folded through LDS (all loads independent)
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s1 = 0, s2 = 0;
-  for (int k = 0; k < slots; ++k) { s1 += (double)ssum[(long)k * C + c]; s2 += (double)ssq[(long)k * C + c]; }
+  if (c < C)
+    for (int k = sg; k < slots; k += 8) { s1 += (double)ssum[(long)k * C + c]; s2 += (double)ssq[(long)k * C + c]; }
+  red[0][sg][cl] = s1;
+  red[1][sg][cl] = s2;
+  __syncthreads();
+  if (sg != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
   const double mu = s1 / count;
   double var = s2 / count - mu * mu;
   if (var < 0) var = 0;
@@ -85,7 +95,7 @@ extern "C" int sy11_bn_finalize(int32_t C, int32_t stat_slots, double count, con
   SY11_REQUIRE(C > 0 && count > 0, "bn_finalize: bad C/count");
   SY11_REQUIRE(stat_sum && stat_sq && gamma && beta && mean && rstd && scale && shift, "bn_finalize: null pointer");
   SY11_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must both be given or both NULL");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, C, stat_slots > 1 ? stat_slots : 1, count, stat_sum, stat_sq, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, C, stat_slots > 1 ? stat_slots : 1, count, stat_sum, stat_sq, gamma,
                      beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
   SY11_LAUNCH_CHECK("bn_finalize");
   return SY11_OK;
@@ -261,37 +271,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const 
                                                            const float* __restrict__ sum_gx, T* __restrict__ dy, int dy_ld, float* dgamma,
                                                            float* dbeta, int cpv, int rows_pb, int slots) {
   constexpr int U = 4;
+  __shared__ float s_tot[2][256 * VEC];
   const int cw = cpv < 256 ? cpv : 256;
   const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
   const int rsub = threadIdx.x / cw;
+  // fold the partial-sum slots ONCE per workgroup (channel e of this block's range per thread), share through LDS
+  {
+    const int nch = min(cw, cpv - (int)blockIdx.y * 256) * VEC;
+    const int cbase = blockIdx.y * 256 * VEC;
+    for (int e = threadIdx.x; e < nch; e += 256) {
+      float tg = 0.f, tgx = 0.f;
+      for (int k = 0; k < slots; ++k) { tg += sum_g[(long)k * C + cbase + e]; tgx += sum_gx[(long)k * C + cbase + e]; }
+      s_tot[0][e] = tg;
+      s_tot[1][e] = tgx;
+      if (blockIdx.x == 0 && dgamma) { atomicAdd(dgamma + cbase + e, tgx); atomicAdd(dbeta + cbase + e, tg); }
+    }
+  }
+  __syncthreads();
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
+  const int cl0 = (threadIdx.x % cw) * VEC;
   const float invM = 1.0f / (float)M;
   float mu[VEC], rs[VEC], sc[VEC], sh[VEC], k0[VEC], k1[VEC], k2[VEC];
-  // fold the (<= 8) partial-sum slots: all loads issued up front (clamped slot index + 0/1 weight), no dependent chain
-  constexpr int MAXS = 8;
-  float pg[MAXS][VEC], pgx[MAXS][VEC];
-#pragma unroll
-  for (int k = 0; k < MAXS; ++k) {
-    const int kk = k < slots ? k : 0;
-    vload<float, VEC>(sum_g + (long)kk * C + c, pg[k]);
-    vload<float, VEC>(sum_gx + (long)kk * C + c, pgx[k]);
-  }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     mu[i] = mean[c + i]; rs[i] = rstd[c + i]; sc[i] = scale[c + i]; sh[i] = shift[c + i];
-    float tg = 0.f, tgx = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-      const float wk = k < slots ? 1.f : 0.f;
-      tg += pg[k][i] * wk;
-      tgx += pgx[k][i] * wk;
-    }
     const float gr = gamma[c + i] * rs[i];
     k0[i] = gr;
-    k1[i] = gr * tg * invM;
-    k2[i] = gr * tgx * invM;
-    if (blockIdx.x == 0 && rsub == 0 && dgamma) { atomicAdd(dgamma + c + i, tgx); atomicAdd(dbeta + c + i, tg); }
+    k1[i] = gr * s_tot[0][cl0 + i] * invM;
+    k2[i] = gr * s_tot[1][cl0 + i] * invM;
   }
   const long step = (long)gridDim.x * rows_pb;
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += step * U) {
@@ -324,7 +332,6 @@ extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const 
                                      void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && M > 0 && C > 0 && y && dz && dy && mean && rstd && scale && shift && gamma && sum_g && sum_gx, "bn_act_bwd_apply: bad argument");
   SY11_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_act_bwd_apply: dgamma/dbeta both or neither");
-  SY11_REQUIRE(sum_slots <= 8, "bn_act_bwd_apply: at most 8 partial-sum slots");
   SY11_REQUIRE(y_ld >= C && dz_ld >= C && dy_ld >= C, "bn_act_bwd_apply: pixel stride < C");
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {y_ld, dz_ld, dy_ld}, {y, dz, dy});
