@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-stft", action="store_true", help="feed resident (B,3,H,W) images instead of IQ")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel individually instead of hipGraph replay")
     a = ap.parse_args()
 
     from sy11 import _lib
@@ -118,7 +119,7 @@ def main():
     model = DetectionModel(a.model, nc=80, verbose=False)
     producer = SpectrogramProducer(dev, n_frames=a.imgsz, n_mel=a.imgsz) if not a.no_stft else None
     tr = DetectionTrainer(model, batch_size=a.batch, device=dev, overrides={"amp": a.dtype == "f16"}, world_size=world,
-                          producer=producer)
+                          producer=producer, graphs=not a.no_graphs)
     labels = synthetic_labels(a.batch, 100 + rank, dev)
     if producer is not None:
         data = {"iq": synthetic_iq(a.batch, producer.n_samples, 1 + rank, dev)}
@@ -157,6 +158,7 @@ def main():
     roof = None
     if rank == 0 and not a.no_roofline:
         # one instrumented step: every C-ABI launch bracketed by events on the launch stream
+        tr.model.__dict__.pop("_sy11_graph_cfg", None)          # per-launch events need individually launched kernels
         _lib.PROFILE = []
         step()
         torch.cuda.synchronize()

@@ -108,6 +108,7 @@ class Ctx:
         self.pool_off = 0
         self.pool_need = 0
         self.bn_counters: List[torch.Tensor] = []
+        self.capturing = False        # inside hipGraph capture: no host-side caching keyed on parameter versions
 
     def empty(self, B, H, W, Cn, dtype=None):
         return torch.empty((B, H, W, Cn), dtype=dtype or self.dtype, device=self.device)
@@ -128,10 +129,11 @@ class Ctx:
 class GradStore:
     """One flat f32 gradient buffer; every parameter's ``.grad`` is a view of it (conv filters in KRSC memory)."""
 
-    def __init__(self, module: torch.nn.Module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module: torch.nn.Module, order=None):
+        self.params = list(order) if order is not None else [p for p in module.parameters() if p.requires_grad]
         self.flat = None
         self.views = {}
+        self.external_zero = False    # True: the owner (trainer) zeroes ``flat`` itself after each optimizer step
 
     def _build(self, device):
         total = sum(p.numel() for p in self.params)
@@ -154,7 +156,8 @@ class GradStore:
             self._build(device)
         fresh = any(p.grad is None or p.grad.data_ptr() != self.views[id(p)].data_ptr() for p in self.params)
         if fresh:
-            self.flat.zero_()
+            if not (self.external_zero and all(p.grad is not None for p in self.params)):
+                self.flat.zero_()
             for p in self.params:
                 p.grad = self.views[id(p)]
 
@@ -256,7 +259,105 @@ class EngineFn(torch.autograd.Function):
 module_post_backward = {}
 
 
+class _Graphed:
+    """One captured (forward graph, backward graph) pair for a fixed input signature of a module.
+
+    hipGraph replay replaces ~1300 individually launched kernels per training step by two graph launches: the tape's
+    Python closures run ONCE, at capture time; afterwards only device work remains.  Everything the closures touch is
+    static: inputs are copied into ``static_in``, activations live in the graph's private pool, parameter gradients in
+    the GradStore's flat buffer, output gradients are copied into ``static_gout`` before the backward replay.
+    """
+
+    def __init__(self, module, xs, is_list, dtype):
+        dev = xs[0].device
+        store = module.__dict__.get("_sy11_grads")
+        if store is None:
+            store = GradStore(module)
+            module.__dict__["_sy11_grads"] = store
+        store.begin_backward(dev)                                   # flat gradient buffer exists at a fixed address
+        self.store = store
+        self.static_in = [x.detach().clone() for x in xs]
+        self.is_list = is_list
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.g_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fwd, stream=side):
+                ec = Ctx(True, True, dtype, dev, store, module.__dict__.get("_sy11_pool_hint", 0))
+                ec.capturing = True
+                acts = [to_act(t, dtype) for t in self.static_in]
+                out = module._run(ec, acts if is_list else acts[0])
+                if ec.bn_counters:
+                    torch._foreach_add_(ec.bn_counters, 1)
+            self.ec, self.acts = ec, acts
+            self.outs, _ = _flatten(out)
+            self.static_out = [from_act(a) for a in self.outs]
+            self.static_gout = [torch.zeros_like(a.data) for a in self.outs]      # NHWC, activation dtype
+            self.g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), stream=side):
+                for a, g in zip(self.outs, self.static_gout):
+                    if a.data.dim() == 4:
+                        a.set_grad(g)
+                for bw in reversed(ec.tape):
+                    bw()
+                self.static_gin = [a.grad_read().permute(0, 3, 1, 2) if a.req else None for a in acts]
+            ec.tape.clear()
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+
+class GraphFn(torch.autograd.Function):
+    """Autograd bridge over a captured pair: copy in, replay forward; copy output grads in, replay backward."""
+
+    @staticmethod
+    def forward(ctx, entry, n_in, *tensors):
+        for dst, src in zip(entry.static_in, tensors[:n_in]):
+            dst.copy_(src)
+        entry.g_fwd.replay()
+        ctx.entry, ctx.n_in, ctx.n_t = entry, n_in, len(tensors)
+        ctx.in_req = [t.requires_grad for t in tensors[:n_in]]
+        return tuple(o.detach() for o in entry.static_out)          # fresh tensor objects over the static storage
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        e = ctx.entry
+        e.store.begin_backward(e.static_in[0].device)               # zeroes the flat buffer at the start of a window
+        for dst, g in zip(e.static_gout, gouts):
+            if g is not None and dst.dim() == 4:
+                dst.copy_(g.permute(0, 2, 3, 1))
+        e.g_bwd.replay()
+        gin = [(g.float() if (req and g is not None) else None) for g, req in zip(e.static_gin, ctx.in_req)]
+        hook = module_post_backward.get(id(e.store))
+        if hook is not None:
+            hook(e.store)
+        return (None, None, *gin, *([None] * (ctx.n_t - ctx.n_in)))
+
+
+def enable_graphs(module, warmup: int = 2):
+    """Opt a module into hipGraph replay of its train-mode forward/backward (static shapes; see _Graphed)."""
+    module.__dict__["_sy11_graph_cfg"] = {"warmup": warmup, "seen": {}, "entries": {}}
+    return module
+
+
 def run_module(module, x):
+    """nn.Module.forward for any sy11 module: tensor(s) in, tensor(s) out, differentiable through EngineFn."""
+    cfg = module.__dict__.get("_sy11_graph_cfg")
+    if cfg is not None and module.training and torch.is_grad_enabled():
+        xs, is_list = _flatten(x)
+        dtype = engine_dtype(module)
+        key = (tuple((tuple(t.shape), t.dtype) for t in xs), dtype)
+        entry = cfg["entries"].get(key)
+        if entry is None:
+            n = cfg["seen"].get(key, 0)
+            cfg["seen"][key] = n + 1
+            if n >= cfg["warmup"]:
+                entry = cfg["entries"][key] = _Graphed(module, xs, is_list, dtype)
+        if entry is not None:
+            params = [p for p in module.parameters()]
+            return GraphFn.apply(entry, len(xs), *xs, *params)
+    return _run_module_eager(module, x)
+
+
+def _run_module_eager(module, x):
     """nn.Module.forward for any sy11 module: tensor(s) in, tensor(s) out, differentiable through EngineFn."""
     xs, is_list = _flatten(x)
     params = [p for p in module.parameters()]

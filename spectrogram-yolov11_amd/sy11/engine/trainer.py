@@ -20,7 +20,8 @@ DEFAULTS = dict(lr0=0.01, momentum=0.937, weight_decay=0.0005, nbs=64, box=7.5, 
 class DetectionTrainer:
     """One-process-per-GPU trainer for a ``DetectionModel`` (the reference's DetectionTrainer hot path)."""
 
-    def __init__(self, model, batch_size=64, device="cuda", overrides=None, world_size=1, producer=None):
+    def __init__(self, model, batch_size=64, device="cuda", overrides=None, world_size=1, producer=None, graphs=True,
+                 flat=True):
         self.args = SimpleNamespace(**{**DEFAULTS, **(overrides or {})})
         self.device = torch.device(device)
         self.model = model.to(self.device)
@@ -36,11 +37,31 @@ class DetectionTrainer:
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp)
         self.accumulate = max(round(self.args.nbs / (batch_size * world_size)), 1)
         wd = self.args.weight_decay * batch_size * world_size * self.accumulate / self.args.nbs
-        self.optimizer = self.build_optimizer(self.model, self.args.optimizer, self.args.lr0, self.args.momentum, wd)
-        self.ema = ModelEMA(self.model)
+        self.flat = None
+        if flat:
+            # parameters / buffers re-homed into flat buffers; 3 optimizer groups = 3 slices (see engine/flat.py)
+            from . import GradStore
+            from .flat import FlatEMA, FlatState
+            self.flat = FlatState(self.model)
+            store = GradStore(self.model, order=self.flat.order)
+            store.external_zero = True
+            store.begin_backward(self.device)
+            self.model.__dict__["_sy11_grads"] = store
+            self.grad_store = store
+            self.flat_params = [t.requires_grad_(True) for t in self.flat.group_tensors(self.flat.flat)]
+            self.flat_grads = self.flat.group_tensors(store.flat)
+            self.optimizer = self.build_flat_optimizer(self.flat_params, self.args.optimizer, self.args.lr0,
+                                                       self.args.momentum, wd)
+            self.ema = FlatEMA(self.model, self.flat)
+        else:
+            self.optimizer = self.build_optimizer(self.model, self.args.optimizer, self.args.lr0, self.args.momentum, wd)
+            self.ema = ModelEMA(self.model)
         if world_size > 1:
             ddp.broadcast_parameters(self.model)
             ddp.attach(self.model)
+        if graphs:                                          # hipGraph replay of forward/backward after 2 eager steps
+            from . import enable_graphs
+            enable_graphs(self.model)
         self.last_opt_step = -1
         self.ni = 0
 
@@ -70,6 +91,20 @@ class DetectionTrainer:
         opt.add_param_group({"params": g[1], "weight_decay": 0.0})
         return opt
 
+    @staticmethod
+    def build_flat_optimizer(flat_params, name="SGD", lr=0.01, momentum=0.9, decay=1e-5):
+        """Same three groups as build_optimizer, each ONE flat tensor: [decay weights, norm weights, biases]."""
+        w, n, b = flat_params
+        if name in {"Adam", "Adamax", "AdamW", "NAdam", "RAdam"}:
+            opt = getattr(torch.optim, name)([b], lr=lr, betas=(momentum, 0.999), weight_decay=0.0)
+        elif name == "SGD":
+            opt = torch.optim.SGD([b], lr=lr, momentum=momentum, nesterov=True)
+        else:
+            raise NotImplementedError(f"optimizer {name}")
+        opt.add_param_group({"params": [w], "weight_decay": decay})
+        opt.add_param_group({"params": [n], "weight_decay": 0.0})
+        return opt
+
     def preprocess_batch(self, batch):
         """detect/train.py:57-74: uint8 -> float/255; with a producer: raw IQ -> spectrogram image on device."""
         if "iq" in batch and self.producer is not None:
@@ -81,11 +116,20 @@ class DetectionTrainer:
 
     def optimizer_step(self):
         """trainer.py:585-593."""
-        self.scaler.unscale_(self.optimizer)
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10.0)
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
-        self.optimizer.zero_grad()
+        if self.flat is not None:
+            for p, g in zip(self.flat_params, self.flat_grads):
+                p.grad = g                               # flat slices of the GradStore buffer
+            self.scaler.unscale_(self.optimizer)
+            torch.nn.utils.clip_grad_norm_(self.flat_params, max_norm=10.0)      # same elements => same total norm
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+            self.grad_store.flat.zero_()                 # one memset instead of zero_grad over 255 tensors
+        else:
+            self.scaler.unscale_(self.optimizer)
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10.0)
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+            self.optimizer.zero_grad()
         if self.ema:
             self.ema.update(self.model)
 
@@ -96,8 +140,8 @@ class DetectionTrainer:
         batch = self.preprocess_batch(batch)
         loss, items = self.model(batch)
         self.scaler.scale(loss).backward()
-        self.ni += 1
-        if self.ni - self.last_opt_step >= self.accumulate:
+        if self.ni - self.last_opt_step >= self.accumulate:      # trainer.py:391 (ni counts from 0, last_opt_step from -1)
             self.optimizer_step()
             self.last_opt_step = self.ni
+        self.ni += 1
         return loss.detach(), items

@@ -31,23 +31,25 @@ def _int(v):
     return v[0] if isinstance(v, (tuple, list)) else v
 
 
-def working_filter(holder: nn.Module, w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """[O][KH][KW][I] tensor of ``dtype`` for parameter ``w``; cached until the parameter is modified in place."""
+def working_filter(holder: nn.Module, w: torch.Tensor, dtype: torch.dtype, force: bool = False) -> torch.Tensor:
+    """[O][KH][KW][I] tensor of ``dtype`` for parameter ``w``; cached until the parameter is modified in place
+    (``force``: always re-derive — used under hipGraph capture, where the cast must be part of the replayed work)."""
     key = (w._version, w.data_ptr(), dtype, w.device)
     cache = holder.__dict__.get("_sy11_wcache")
-    if cache is not None and cache[0] == key:
+    if not force and cache is not None and cache[0] == key:
         return cache[1]
     k = ops.filter_krsc(w.detach())
     if k.dtype != dtype:
         k = k.to(dtype)
-    holder.__dict__["_sy11_wcache"] = (key, k)
+    if not force:
+        holder.__dict__["_sy11_wcache"] = (key, k)
     return k
 
 
 def conv2d_bias_run(ec: Ctx, conv: nn.Conv2d, x: Act, out: Act) -> Act:
     """Bare nn.Conv2d with bias (Detect's last 1x1 convs, head.py:44-55): writes f32 logits into ``out``."""
     k, s, p, d = _int(conv.kernel_size), _int(conv.stride), _int(conv.padding), _int(conv.dilation)
-    w = working_filter(conv, conv.weight, ec.dtype)
+    w = working_filter(conv, conv.weight, ec.dtype, ec.capturing)
     bias = conv.bias.detach().float() if conv.bias is not None else None
     out_f32 = out.data.dtype == torch.float32 and ec.dtype != torch.float32
     ops.conv2d_fwd(x.data, w, out.data, k, s, p, d, 1, bias=bias, out_f32=out_f32)
@@ -119,7 +121,7 @@ class Conv(nn.Module):
         N = conv.out_channels
         OH, OW = ops.conv_out_hw(H, W, k, s, p, d)
         silu = self._silu()
-        w = working_filter(conv, conv.weight, ec.dtype)
+        w = working_filter(conv, conv.weight, ec.dtype, ec.capturing)
         stem = x.raw is not None and C1 == 3 and k == 3 and g == 1 and d == 1 and N <= 64
         if out is None:
             out = Act(ec.empty(B, OH, OW, N))
