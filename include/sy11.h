@@ -147,6 +147,25 @@ int sy11_nms_sorted(int32_t n, const float* boxes, float iou_thres, uint64_t* wo
                     void* stream);
 size_t sy11_nms_workspace_bytes(int32_t n);
 
+/* ---- fused detection criterion (v8DetectionLoss.__call__, utils/loss.py:221-275; TaskAlignedAssigner, utils/tal.py:40-296;
+ *      bbox_iou CIoU, utils/metrics.py:171-234).  maps: nl NHWC f32 head maps (B, H_l*W_l, 64+nc); gt: (B, G, 5) rows
+ *      [cls, x1, y1, x2, y2] in pixels, all-zero rows are padding.  Workspaces are caller-allocated:
+ *      pbox (B,A,4) f32, align/overlap (B,G,A) f32, topk (B,G,10) i32, assign (B,A) i32, pos (2,B,G) f32 zeroed,
+ *      norm (B,A) f32, sums (64,4) f32 zeroed: per-slot partials of {sum(target_scores), box, cls, dfl}.            */
+int sy11_det_loss_assign(int32_t B, int32_t nc, int32_t nl, const float* const* maps, const int32_t* hs, const int32_t* ws,
+                         const float* strides, int32_t G, const float* gt, float* pbox, float* align, float* overlap,
+                         int32_t* topk, int32_t* assign, float* pos, float* norm, float* sums, void* stream);
+/* un-normalised loss sums: sums[.][1..3] += sum (1-CIoU)*w, sum BCE, sum DFL*w                                      */
+int sy11_det_loss_terms(int32_t B, int32_t nc, int32_t nl, const float* const* maps, const int32_t* hs, const int32_t* ws,
+                        const float* strides, int32_t G, const float* gt, const int32_t* assign, const float* norm,
+                        float* sums, void* stream);
+/* dmaps[l] = d(B * (gb*box + gc*cls + gd*dfl) / tss) / d maps[l], scaled by the DEVICE scalar *upstream_over_tss
+ * (= upstream gradient / max(tss, 1)); no host synchronisation.                                                    */
+int sy11_det_loss_bwd(int32_t B, int32_t nc, int32_t nl, const float* const* maps, float* const* dmaps, const int32_t* hs,
+                      const int32_t* ws, const float* strides, int32_t G, const float* gt, const int32_t* assign,
+                      const float* norm, const float* upstream_over_tss, float gain_box, float gain_cls, float gain_dfl,
+                      void* stream);
+
 /* ---- IQ -> STFT -> power -> mel -> log producer (no reference code: README.md:7; spec in DESIGN.md) ------ */
 /* iq: (B, L) interleaved complex64; db: (B, n_frames, n_mel) f32 dB (frame-major: coalesced stores);
  * minmax: (B,2) f32 [min,max] per image

@@ -52,6 +52,9 @@ SIGNATURES = {
     "sy11_attention_bwd": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
     "sy11_detect_decode": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_nms_sorted": [_i32, _vp, _f32, _vp, _vp, _vp],
+    "sy11_det_loss_assign": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sy11_det_loss_terms": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    "sy11_det_loss_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp],
     "sy11_stft_logmel": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "sy11_stft_minmax_init": [_i32, _vp, _vp],
     "sy11_stft_normalize": [_i32, _i32, _i32, _vp, _vp, _vp, _vp],

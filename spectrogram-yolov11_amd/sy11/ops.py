@@ -267,3 +267,55 @@ def stft_normalize(db, mm):
     img = torch.empty((B, 3, n_mel, n_frames), dtype=torch.float32, device=db.device)
     call("sy11_stft_normalize", B, n_mel, n_frames, _p(db), _p(mm), _p(img), _stream())
     return img
+
+
+class DetLossWorkspace:
+    """Device buffers of one fused-loss evaluation (kept for the backward launch)."""
+
+    def __init__(self, maps, strides, nc, gt):
+        self.maps = maps
+        self.nl = len(maps)
+        self.B = maps[0].shape[0]
+        self.nc = nc
+        self.G = gt.shape[1]
+        self.gt = gt.contiguous().float()
+        dev = maps[0].device
+        self.A = sum(m.shape[1] * m.shape[2] for m in maps)
+        self.ptrs = (C.c_void_p * self.nl)(*[m.data_ptr() for m in maps])
+        self.hs = (C.c_int32 * self.nl)(*[m.shape[1] for m in maps])
+        self.ws = (C.c_int32 * self.nl)(*[m.shape[2] for m in maps])
+        self.st = (C.c_float * self.nl)(*[float(s) for s in strides])
+        B, A, G = self.B, self.A, max(self.G, 1)
+        self.pbox = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+        self.align = torch.empty((B, G, A), dtype=torch.float32, device=dev)
+        self.overlap = torch.empty((B, G, A), dtype=torch.float32, device=dev)
+        self.topk = torch.empty((B, G, 10), dtype=torch.int32, device=dev)
+        self.assign = torch.empty((B, A), dtype=torch.int32, device=dev)
+        self.norm = torch.empty((B, A), dtype=torch.float32, device=dev)
+        self.zero = torch.zeros(2 * B * G + 256, dtype=torch.float32, device=dev)      # pos maxima + sums, one memset
+        self.pos = self.zero[: 2 * B * G]
+        self.sums = self.zero[2 * B * G:].view(64, 4)
+
+
+def det_loss_forward(maps, strides, nc, gt):
+    """maps: contiguous NHWC f32 (B,H,W,64+nc) list; gt (B,G,5).  -> (workspace, sums (64,4) device tensor)."""
+    _need_gpu(*maps, gt)
+    for m in maps:
+        if m.dtype != torch.float32 or not m.is_contiguous() or m.shape[-1] != 64 + nc:
+            raise _lib.Sy11Error("det_loss: maps must be contiguous NHWC f32 with 64+nc channels")
+    w = DetLossWorkspace(maps, strides, nc, gt)
+    cast = lambda a: C.cast(a, C.c_void_p)
+    call("sy11_det_loss_assign", w.B, nc, w.nl, cast(w.ptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt), _p(w.pbox),
+         _p(w.align), _p(w.overlap), _p(w.topk), _p(w.assign), _p(w.pos), _p(w.norm), _p(w.sums), _stream())
+    call("sy11_det_loss_terms", w.B, nc, w.nl, cast(w.ptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt), _p(w.assign),
+         _p(w.norm), _p(w.sums), _stream())
+    return w
+
+
+def det_loss_backward(w: DetLossWorkspace, upstream_over_tss: torch.Tensor, gains):
+    dmaps = [torch.empty_like(m) for m in w.maps]
+    dptrs = (C.c_void_p * w.nl)(*[d.data_ptr() for d in dmaps])
+    cast = lambda a: C.cast(a, C.c_void_p)
+    call("sy11_det_loss_bwd", w.B, w.nc, w.nl, cast(w.ptrs), cast(dptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt),
+         _p(w.assign), _p(w.norm), _p(upstream_over_tss), float(gains[0]), float(gains[1]), float(gains[2]), _stream())
+    return dmaps

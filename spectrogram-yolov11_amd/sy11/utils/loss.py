@@ -45,10 +45,45 @@ class BboxLoss(nn.Module):
         return loss_iou, loss_dfl
 
 
-class v8DetectionLoss:
-    """box (CIoU) + cls (BCE) + dfl, returned as (sum * batch_size, detached items)."""
+class _FusedLossFn(torch.autograd.Function):
+    """Whole criterion as 5 HIP launches forward + 1 backward (csrc/loss.hip); no host synchronisation."""
 
-    def __init__(self, model, tal_topk=10):
+    @staticmethod
+    def forward(ctx, crit, gt, *feats):
+        from .. import ops as K
+        maps = [f.permute(0, 2, 3, 1) for f in feats]
+        maps = [m if m.is_contiguous() else m.contiguous() for m in maps]
+        w = K.det_loss_forward(maps, [float(s) for s in crit.stride], crit.nc, gt)
+        tot = w.sums.sum(0)                                     # [tss, box, cls, dfl]
+        tss = tot[0].clamp(min=1.0)
+        items = tot[1:4] / tss
+        gains = torch.tensor([crit.hyp.box, crit.hyp.cls, crit.hyp.dfl], dtype=torch.float32).to(items.device, non_blocking=True) \
+            if crit._gains is None else crit._gains
+        crit._gains = gains
+        items = items * gains
+        ctx.w, ctx.tss, ctx.crit = w, tss, crit
+        loss = items.sum() * feats[0].shape[0]
+        ctx.mark_non_differentiable(items)
+        return loss, items
+
+    @staticmethod
+    def backward(ctx, gloss, gitems):
+        from .. import ops as K
+        crit = ctx.crit
+        up = (gloss.float() / ctx.tss).reshape(1).contiguous()
+        dmaps = K.det_loss_backward(ctx.w, up, (crit.hyp.box, crit.hyp.cls, crit.hyp.dfl))
+        return (None, None, *[d.permute(0, 3, 1, 2) for d in dmaps])
+
+
+class v8DetectionLoss:
+    """box (CIoU) + cls (BCE) + dfl, returned as (sum * batch_size, detached items).
+
+    On the MI355X the criterion runs as fused HIP kernels (``fused=True``, default when the maps are CUDA f32 tensors with
+    reg_max 16 and top-k 10); ``fused=False`` keeps the tensor-op formulation of the reference (device agnostic)."""
+
+    def __init__(self, model, tal_topk=10, fused=True):
+        self.fused = fused and tal_topk == 10
+        self._gains = None
         device = next(model.parameters()).device
         h = model.args
         m = model.model[-1]
@@ -88,9 +123,15 @@ class v8DetectionLoss:
         return dist2bbox(pred_dist, anchor_points, xywh=False)
 
     def __call__(self, preds, batch):
-        loss = torch.zeros(3, device=self.device)
         feats = preds[1] if isinstance(preds, tuple) else preds
         B = feats[0].shape[0]
+        if self.fused and self.reg_max == 16 and all(f.is_cuda and f.dtype == torch.float32 for f in feats):
+            imgsz = torch.tensor(feats[0].shape[2:], dtype=torch.float32) * float(self.stride[0])
+            targets = torch.cat((batch["batch_idx"].view(-1, 1), batch["cls"].view(-1, 1), batch["bboxes"]), 1)
+            gt = self.preprocess(targets.to(self.device).float(), B, scale_tensor=imgsz[[1, 0, 1, 0]].to(self.device))
+            loss, items = _FusedLossFn.apply(self, gt, *feats)
+            return loss, items.detach()
+        loss = torch.zeros(3, device=self.device)
         # (B, no, H, W) with NHWC memory -> (B, H*W, no) without a copy; fall back to permute for NCHW-contiguous input
         flat = [xi.permute(0, 2, 3, 1).reshape(B, -1, self.no) for xi in feats]
         cat = torch.cat(flat, 1).float()
