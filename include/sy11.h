@@ -75,6 +75,12 @@ int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const void* dy, in
 /* wt[c][t][n] = w[n][t][c]  (t = r*KW+s), same dtype; feeds sy11_conv2d_dgrad                               */
 int sy11_weight_transpose(int32_t dtype, int32_t N, int32_t T, int32_t C, const void* w, void* wt, void* stream);
 
+/* every dgrad filter of a model in one launch.  desc: device array of nlayers records
+ * {int32 N, T, C, pad; int64 src_off, dst_off (elements into src / dst); int32 first_tile, tiles_c, tiles_n, pad}
+ * sorted by first_tile; a layer owns T * tiles_n * tiles_c tiles of 32x32 (tiles_x = ceil(x/32)).                */
+int sy11_weight_transpose_multi(int32_t dtype, int32_t nlayers, int32_t total_tiles, const void* desc, const void* src,
+                                void* dst, void* stream);
+
 /* first layer: x is the caller's NCHW f32 image (B,3,H,W) in [0,1] (detect/train.py:59 output); y NHWC.    */
 int sy11_stem_conv_fwd(const sy11_conv_desc* d, const float* x_nchw, const void* w, const float* bias, void* y,
                        float* stat_sum, float* stat_sq, void* stream);

@@ -565,3 +565,46 @@ extern "C" int sy11_weight_transpose(int32_t dtype, int32_t N, int32_t T_, int32
   SY11_LAUNCH_CHECK("weight_transpose");
   return SY11_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ batched weight transpose
+// All dgrad filters of a model in ONE launch: desc[l] = {N, T, C, src_off, dst_off, first_tile} over flat buffers.
+struct WtDesc { int N, T, C, pad; long src_off, dst_off; int first_tile, tiles_c, tiles_n, pad2; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_transpose_multi_kernel(int nlayers, const WtDesc* __restrict__ desc, const T* __restrict__ src,
+                                                                     T* __restrict__ dst) {
+  __shared__ T tile[32][33];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = nlayers - 1;                   // last layer whose first_tile <= bid
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].first_tile <= bid) lo = mid; else hi = mid - 1;
+  }
+  const WtDesc d = desc[lo];
+  int rel = bid - d.first_tile;
+  const int per_tap = d.tiles_c * d.tiles_n;
+  const int t = rel / per_tap;
+  rel -= t * per_tap;
+  const int n0 = (rel / d.tiles_c) * 32, c0 = (rel % d.tiles_c) * 32;
+  const T* w = src + d.src_off;
+  T* wt = dst + d.dst_off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int n = n0 + j, c = c0 + tx;
+    tile[j][tx] = (n < d.N && c < d.C) ? w[((long)n * d.T + t) * d.C + c] : (T)0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, n = n0 + tx;
+    if (c < d.C && n < d.N) wt[((long)c * d.T + t) * d.N + n] = tile[tx][j];
+  }
+}
+
+extern "C" int sy11_weight_transpose_multi(int32_t dtype, int32_t nlayers, int32_t total_tiles, const void* desc, const void* src,
+                                           void* dst, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && nlayers > 0 && total_tiles > 0 && desc && src && dst, "weight_transpose_multi: bad argument");
+  SY11_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((weight_transpose_multi_kernel<T>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                                                   nlayers, (const WtDesc*)desc, (const T*)src, (T*)dst));
+  SY11_LAUNCH_CHECK("weight_transpose_multi");
+  return SY11_OK;
+}

@@ -35,6 +35,7 @@ SIGNATURES = {
     "sy11_conv2d_dgrad": [_dp, _vp, _i32, _vp, _vp, _vp],
     "sy11_conv2d_wgrad": [_dp, _vp, _vp, _i32, _vp, _vp],
     "sy11_weight_transpose": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "sy11_weight_transpose_multi": [_i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "sy11_stem_conv_fwd": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_stem_conv_wgrad": [_dp, _vp, _vp, _i32, _vp, _vp],
     "sy11_bn_finalize": [_i32, _i32, _f64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -109,6 +109,27 @@ class Ctx:
         self.pool_need = 0
         self.bn_counters: List[torch.Tensor] = []
         self.capturing = False        # inside hipGraph capture: no host-side caching keyed on parameter versions
+        self.w_views = None           # {id(param): working-dtype [O][KH][KW][I] view} from ONE flat cast (trainer's FlatState)
+        self.wt_views = None          # {id(param): tap-transposed view}, built lazily at the start of backward
+        self.w_bank = None
+        self.flat_state = None
+
+    def attach_flat(self, module):
+        """Trainer-provided FlatState: derive all working-dtype filters with one cast (and later one transpose) launch."""
+        fs = module.__dict__.get("_sy11_flat")
+        if fs is not None and self.training:
+            self.flat_state = fs
+            self.w_bank, self.w_views = fs.working_views(self.dtype)
+
+    def transposed(self, p, w_krsc):
+        """Tap-transposed filter for dgrad: from the batched bank when available, else a per-layer transpose."""
+        if self.flat_state is not None:
+            if self.wt_views is None:
+                self.wt_views = self.flat_state.transposed_views(self.w_bank)
+            v = self.wt_views.get(id(p))
+            if v is not None:
+                return v
+        return ops.weight_transpose(w_krsc)
 
     def empty(self, B, H, W, Cn, dtype=None):
         return torch.empty((B, H, W, Cn), dtype=dtype or self.dtype, device=self.device)
@@ -215,6 +236,7 @@ class EngineFn(torch.autograd.Function):
                 store = GradStore(module)
                 module.__dict__["_sy11_grads"] = store
         ec = Ctx(module.training, record, dtype, ins[0].device, store, module.__dict__.get("_sy11_pool_hint", 0))
+        ec.attach_flat(module)
         acts = [to_act(t, dtype) for t in ins]
         out = module._run(ec, acts if is_list else acts[0])
         if ec.bn_counters:
@@ -285,6 +307,7 @@ class _Graphed:
             with torch.cuda.graph(self.g_fwd, stream=side):
                 ec = Ctx(True, True, dtype, dev, store, module.__dict__.get("_sy11_pool_hint", 0))
                 ec.capturing = True
+                ec.attach_flat(module)
                 acts = [to_act(t, dtype) for t in self.static_in]
                 out = module._run(ec, acts if is_list else acts[0])
                 if ec.bn_counters:

@@ -69,8 +69,57 @@ class FlatState:
             b.data = v
             off += n
 
+        self.offsets = {}
+        off = 0
+        for p in self.order:
+            self.offsets[id(p)] = off
+            off += p.numel()
+        self._wt_desc = None
+
     def group_tensors(self, flat: torch.Tensor):
         return [flat[a:b] for a, b in self.group_slices]
+
+    # ---- per-step derived weight banks (one launch each instead of one per layer)
+    def working_views(self, dtype):
+        """{id(param): [O][KH][KW][I] view} over ONE cast of the flat buffer (f32: the flat buffer itself)."""
+        bank = self.flat if dtype == torch.float32 else self.flat.to(dtype)
+        out = {}
+        for p in self.order:
+            if p.dim() == 4:
+                o, i, kh, kw = p.shape
+                a = self.offsets[id(p)]
+                out[id(p)] = bank[a:a + p.numel()].view(o, kh, kw, i)
+        return bank, out
+
+    def transposed_views(self, bank: torch.Tensor):
+        """{id(param): [I][KH][KW][O] view} of every groups==1 conv filter, produced by one batched transpose launch."""
+        import ctypes as C
+        import numpy as np
+        from .. import _lib, ops
+        if self._wt_desc is None:
+            rec = np.dtype([("N", "<i4"), ("T", "<i4"), ("C", "<i4"), ("pad", "<i4"), ("src", "<i8"), ("dst", "<i8"),
+                            ("first", "<i4"), ("tc", "<i4"), ("tn", "<i4"), ("pad2", "<i4")])
+            rows, tiles, self._wt_params = [], 0, []
+            for p in self.order:
+                if p.dim() == 4 and getattr(p, "_sy11_groups", 1) == 1:
+                    o, i, kh, kw = p.shape
+                    tc, tn = -(-i // 32), -(-o // 32)
+                    a = self.offsets[id(p)]
+                    rows.append((o, kh * kw, i, 0, a, a, tiles, tc, tn, 0))
+                    tiles += kh * kw * tc * tn
+                    self._wt_params.append(p)
+            arr = np.array(rows, dtype=rec)
+            self._wt_desc = torch.from_numpy(arr.view(np.uint8).copy()).to(self.flat.device)
+            self._wt_tiles = tiles
+        dst = torch.empty_like(bank)
+        _lib.call("sy11_weight_transpose_multi", ops.dt_code(bank.dtype), len(self._wt_params), self._wt_tiles,
+                  C.c_void_p(self._wt_desc.data_ptr()), C.c_void_p(bank.data_ptr()), C.c_void_p(dst.data_ptr()), ops._stream())
+        out = {}
+        for p in self._wt_params:
+            o, i, kh, kw = p.shape
+            a = self.offsets[id(p)]
+            out[id(p)] = dst[a:a + p.numel()].view(i, kh, kw, o)
+        return out
 
 
 class FlatEMA:

@@ -47,6 +47,7 @@ class DetectionTrainer:
             store.external_zero = True
             store.begin_backward(self.device)
             self.model.__dict__["_sy11_grads"] = store
+            self.model.__dict__["_sy11_flat"] = self.flat
             self.grad_store = store
             self.flat_params = [t.requires_grad_(True) for t in self.flat.group_tensors(self.flat.flat)]
             self.flat_grads = self.flat.group_tensors(store.flat)

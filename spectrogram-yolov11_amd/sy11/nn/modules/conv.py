@@ -49,7 +49,9 @@ def working_filter(holder: nn.Module, w: torch.Tensor, dtype: torch.dtype, force
 def conv2d_bias_run(ec: Ctx, conv: nn.Conv2d, x: Act, out: Act) -> Act:
     """Bare nn.Conv2d with bias (Detect's last 1x1 convs, head.py:44-55): writes f32 logits into ``out``."""
     k, s, p, d = _int(conv.kernel_size), _int(conv.stride), _int(conv.padding), _int(conv.dilation)
-    w = working_filter(conv, conv.weight, ec.dtype, ec.capturing)
+    w = ec.w_views.get(id(conv.weight)) if ec.w_views else None
+    if w is None:
+        w = working_filter(conv, conv.weight, ec.dtype, ec.capturing)
     bias = conv.bias.detach().float() if conv.bias is not None else None
     out_f32 = out.data.dtype == torch.float32 and ec.dtype != torch.float32
     ops.conv2d_fwd(x.data, w, out.data, k, s, p, d, 1, bias=bias, out_f32=out_f32)
@@ -82,7 +84,8 @@ def conv2d_bias_run(ec: Ctx, conv: nn.Conv2d, x: Act, out: Act) -> Act:
                     gs.grad_krsc(conv.weight).add_(dwp[:n])
             if x.req:
                 g, acc = x.grad_for_write()
-                ops.conv2d_dgrad(dy, ops.weight_transpose(wk), g, tuple(dy.shape), k, s, p, d, 1, accumulate=acc)
+                wtr = ec.transposed(conv.weight, wk) if wk is w else ops.weight_transpose(wk)
+                ops.conv2d_dgrad(dy, wtr, g, tuple(dy.shape), k, s, p, d, 1, accumulate=acc)
         ec.tape.append(bw)
     return out
 
@@ -98,6 +101,7 @@ class Conv(nn.Module):
         self.bn = nn.BatchNorm2d(c2)
         self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
         self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
+        self.conv.weight._sy11_groups = g
 
     # ---- torch-facing API (tensor in / tensor out, differentiable)
     def forward(self, x):
@@ -121,7 +125,9 @@ class Conv(nn.Module):
         N = conv.out_channels
         OH, OW = ops.conv_out_hw(H, W, k, s, p, d)
         silu = self._silu()
-        w = working_filter(conv, conv.weight, ec.dtype, ec.capturing)
+        w = ec.w_views.get(id(conv.weight)) if ec.w_views else None
+        if w is None:
+            w = working_filter(conv, conv.weight, ec.dtype, ec.capturing)
         stem = x.raw is not None and C1 == 3 and k == 3 and g == 1 and d == 1 and N <= 64
         if out is None:
             out = Act(ec.empty(B, OH, OW, N))
@@ -189,7 +195,7 @@ class Conv(nn.Module):
                         if s > 1 and k < s and not acc:
                             gx.zero_()
                             acc = True
-                        ops.conv2d_dgrad(dy, ops.weight_transpose(w), gx, (B, OH, OW, N), k, s, p, d, 1, accumulate=acc)
+                        ops.conv2d_dgrad(dy, ec.transposed(conv.weight, w), gx, (B, OH, OW, N), k, s, p, d, 1, accumulate=acc)
                     else:
                         ops.conv2d_dgrad(dy, w, gx, (B, OH, OW, N), k, s, p, d, g, accumulate=acc)
             ec.tape.append(bw)
