@@ -91,7 +91,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--model", default="yolo11s.yaml")
@@ -109,7 +109,9 @@ def main():
     from sy11.engine.trainer import DetectionTrainer
     from sy11.nn.tasks import DetectionModel
 
-    rank, local, world = ddp.setup_process_group()
+    rank, local, world = ddp.setup_process_group(os.environ.get("SY11_DDP_BACKEND"))
+    if "SY11_FORCE_DEVICE" in os.environ:                  # rehearsal of the N>1 path on a one-GPU box (gloo backend)
+        local = int(os.environ["SY11_FORCE_DEVICE"])
     if world != a.gpus and a.gpus > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
@@ -180,7 +182,7 @@ def main():
                                          "desc": (meta or {}).get("desc") if name.startswith(("sy11_conv2d", "sy11_stem")) else None}) + "\n")
         top = max(fam.items(), key=lambda kv: kv[1]["ms"])
         name, f = top
-        peak = PEAK_TFLOPS[a.dtype if name != "sy11_conv2d_wgrad" else "f32"]   # round-1 wgrad runs the f32 MFMA
+        peak = PEAK_TFLOPS[a.dtype]
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
         roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": None, "launches": f["n"],

@@ -54,14 +54,57 @@ class BaseModel(nn.Module):
             return outs[0], list(outs[1:])
         return outs[0]
 
+    def _concat_plan(self):
+        """layer index -> (concat layer index, channel offset): producers write straight into the concat buffer of their
+        (single) consuming Concat, so the model-level torch.cat (conv.py:1821) costs no copy and no extra backward pass."""
+        plan = self.__dict__.get("_sy11_cat_plan")
+        if plan is not None:
+            return plan
+        plan, widths = {}, {}
+        layers = list(self.model)
+        for m in layers:
+            if isinstance(m, Concat) and m.d == 1 and not isinstance(m.f, int):
+                srcs = [(m.i - 1 if j == -1 else j) for j in m.f]
+                chans = [getattr(layers[s], "c_out", None) for s in srcs]
+                ok = all(c is not None for c in chans) and len(set(srcs)) == len(srcs) and not any(s in plan for s in srcs) \
+                    and all(isinstance(layers[s], (Conv, C2f, C3, SPPF, C2PSA, nn.Upsample)) for s in srcs)
+                if ok:
+                    off = 0
+                    for s_, c in zip(srcs, chans):
+                        plan[s_] = (m.i, off)
+                        off += c
+                    widths[m.i] = off
+        self.__dict__["_sy11_cat_plan"] = plan
+        self.__dict__["_sy11_cat_width"] = widths
+        return plan
+
     def _run(self, ec: Ctx, x: Act):
-        """tasks.py:174-188 on engine activations; Upsample+Concat run as 'write into the concat buffer'."""
+        """tasks.py:174-188 on engine activations; Upsample / Concat run as 'write into the concat buffer'."""
+        plan = self._concat_plan()
+        widths = self.__dict__["_sy11_cat_width"]
+        cats = {}
         y = []
         for m in self.model:
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            out = None
+            if m.i in plan:
+                j, off = plan[m.i]
+                B, H, W, _ = x.shape
+                if isinstance(m, nn.Upsample):
+                    H, W = 2 * H, 2 * W
+                elif isinstance(m, Conv):
+                    cv = m.conv
+                    H, W = ops.conv_out_hw(H, W, cv.kernel_size[0], cv.stride[0], cv.padding[0], cv.dilation[0])
+                if j not in cats:
+                    cats[j] = Act(ec.empty(B, H, W, widths[j]))
+                out = cats[j].slice(off, off + m.c_out)
             if isinstance(m, nn.Upsample):
-                x = _upsample_run(ec, m, x)
+                x = _upsample_run(ec, m, x, out)
+            elif isinstance(m, Concat) and m.i in cats:
+                x = cats[m.i]                       # every source already lives in this buffer
+            elif out is not None:
+                x = m._run(ec, x, out=out)
             else:
                 x = m._run(ec, x)
             y.append(x if m.i in self.save else None)
@@ -112,11 +155,12 @@ class BaseModel(nn.Module):
         raise NotImplementedError("compute_loss() needs to be implemented by task heads")
 
 
-def _upsample_run(ec: Ctx, m: nn.Upsample, x: Act) -> Act:
+def _upsample_run(ec: Ctx, m: nn.Upsample, x: Act, out: Act = None) -> Act:
     if m.mode != "nearest" or float(m.scale_factor) != 2.0:
         raise ops._lib.Sy11Error("only nn.Upsample(None, 2, 'nearest') has a HIP kernel")
     B, H, W, Cn = x.shape
-    out = Act(ec.empty(B, 2 * H, 2 * W, Cn))
+    if out is None:
+        out = Act(ec.empty(B, 2 * H, 2 * W, Cn))
     ops.upsample2x_fwd(x.data, out.data)
     if ec.record:
         def bw():
@@ -238,6 +282,7 @@ def parse_model(d, ch, verbose=True):
         t = str(m)[8:-2].replace("__main__.", "")
         m_.np = sum(x.numel() for x in m_.parameters())
         m_.i, m_.f, m_.type = i, f, t
+        m_.c_out = c2                                  # output channels (concat planning)
         save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
         layers.append(m_)
         if i == 0:
