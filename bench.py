@@ -184,8 +184,15 @@ def main():
         name, f = top
         peak = PEAK_TFLOPS[a.dtype]
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
+        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process)
+        tj = ROOT / "profiles" / "r01" / "traffic.json"
+        if tj.exists():
+            fam_t = json.loads(tj.read_text()).get("families", {}).get(name)
+            if fam_t:
+                traffic = round(fam_t["bytes_per_launch"])
         roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches": f["n"],
+                "frac": round(ach / peak, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(f["bytes"] / max(f["n"], 1)), "launches": f["n"],
                 "avg_launch_ms": round(f["ms"] / max(f["n"], 1), 4),
                 "families_ms": {k: round(v["ms"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
 

@@ -39,6 +39,7 @@ struct IgemmArgs {
   int tiles_n;
   int stat_slots;
   unsigned x_bytes, w_bytes;   // extents of the x / w views in bytes (buffer descriptors range-check against them)
+  int debug;              // diagnostic builds only: 1 = skip the LDS-DMA issue after the prologue, 2 = skip the MFMAs
   int vec_out;            // 1: output rows are 16-byte addressable -> LDS-transposed wide stores
   unsigned flags;
   signed char tap_dy[64];
@@ -237,8 +238,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (s + NST - 1 < nstage) issue_stage(smem + ((u + NST - 1) % NST) * STAGE);
-        consume(smem + u * STAGE);
+        if (s + NST - 1 < nstage && a.debug != 1) issue_stage(smem + ((u + NST - 1) % NST) * STAGE);
+        if (a.debug != 2) consume(smem + u * STAGE);
       }
     }
   }
@@ -384,6 +385,9 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
   const long nwg = (long)tiles_m * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg), block(256);
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("SY11_IGEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+  a.debug = dbg;
   static int variant = -1;                       // SY11_IGEMM_VARIANT: 0 = 128-byte stages x2 (2 WG/CU), 1 = 64-byte stages x2 (4 WG/CU)
   if (variant < 0) { const char* e = getenv("SY11_IGEMM_VARIANT"); variant = e ? atoi(e) : 1; }
   // epilogue specialisation: the common flag sets get branch-free code, anything else the runtime-flag build (EPI = -1)
