@@ -72,9 +72,8 @@ template <int KB> __device__ __forceinline__ int swz(int r) { return KB == 128 ?
 
 // EPI: compile-time epilogue (bit 0 stats, 1 bias, 2 SiLU, 3 accumulate, 4 f32 output) or -1 = decide from runtime flags.
 // Small-K layers (1x1 convs, K = 64..192) spend most of their instructions in the epilogue, so its dead branches matter.
-template <typename T, int BN, int WM, int WN, int KB, int NST, int EPI>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
-  constexpr int BM = 128;
+template <typename T, int BM, int BN, int WM, int WN, int KB, int NST, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ? 2 : 1))) void igemm_kernel(const IgemmArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int CPRW = KB / 16;             // 16-byte chunks per LDS row
   constexpr int BK = CPRW * EPC;            // elements of K per stage
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 // ------------------------------------------------------------------------------------------------ host side
 template <typename T>
 static int launch_igemm(IgemmArgs& a, hipStream_t st) {
-  const int tiles_m = cdiv(a.M, 128);
+  int tiles_m = cdiv(a.M, 128);
   {
     const long esz = (long)sizeof(T);
     const long rows_in = (long)(a.M / (a.OH * a.OW)) * a.IH * a.IW;
@@ -381,7 +380,20 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
     a.vec_out = (((uintptr_t)a.y & 15) == 0) && (((long)a.y_ld * osz) % 16 == 0) && (((long)a.N * osz) % 16 == 0);
   }
   int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  // small problems (20x20 / 40x40 maps): a 128-wide tile leaves CUs idle, so narrow the tile until the grid fills the chip
+  static int min_wg = -1;
+  if (min_wg < 0) { const char* e = getenv("SY11_IGEMM_MIN_WG"); min_wg = e ? atoi(e) : 512; }
+  while (bn > 32 && (long)tiles_m * cdiv(a.N, bn) < min_wg) bn >>= 1;
   a.tiles_n = cdiv(a.N, bn);
+  // big layers: a 256-pixel tile (wave tile 128x64) halves the filter traffic per FLOP and the LDS reads per MFMA
+  static int bm256_wg = -1;
+  // off by default: measured slower than 128x128 (r01 sweep) until the k-loop is software-pipelined
+  if (bm256_wg < 0) { const char* e = getenv("SY11_IGEMM_BM256_WG"); bm256_wg = e ? atoi(e) : 0x7fffffff; }
+  const int epi_pre = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
+                      ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
+  const bool bm256 = bn == 128 && std::is_same<T, _Float16>::value && (epi_pre == 0 || epi_pre == 1 || epi_pre == 8) &&
+                     (long)cdiv(a.M, 256) * a.tiles_n >= bm256_wg;
+  if (bm256) tiles_m = cdiv(a.M, 256);
   const long nwg = (long)tiles_m * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg), block(256);
@@ -396,8 +408,8 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
   if (sizeof(T) == 2 && !std::is_same<T, _Float16>::value) epi = -1;          // bf16: generic build only
 #define SY11_IGV(BNN, WMM, WNN, EE)                                                                                  \
   do {                                                                                                               \
-    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, BNN, WMM, WNN, 128, 2, EE>), grid, block, 0, st, a);       \
-    else hipLaunchKernelGGL((igemm_kernel<T, BNN, WMM, WNN, 64, 2, EE>), grid, block, 0, st, a);                     \
+    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, 128, BNN, WMM, WNN, 128, 2, EE>), grid, block, 0, st, a);  \
+    else hipLaunchKernelGGL((igemm_kernel<T, 128, BNN, WMM, WNN, 64, 2, EE>), grid, block, 0, st, a);                \
   } while (0)
 #define SY11_IG(BNN, WMM, WNN)                                   \
   do {                                                           \
@@ -411,7 +423,13 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
       default: SY11_IGV(BNN, WMM, WNN, -1); break;               \
     }                                                            \
   } while (0)
-  if (bn == 128) SY11_IG(128, 2, 2);
+  if (bm256) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+      if (epi_pre == 0) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 0>), grid, block, 0, st, a);
+      else if (epi_pre == 1) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 1>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 8>), grid, block, 0, st, a);
+    }
+  } else if (bn == 128) SY11_IG(128, 2, 2);
   else if (bn == 64) SY11_IG(64, 4, 1);
   else SY11_IG(32, 4, 1);
 #undef SY11_IGV

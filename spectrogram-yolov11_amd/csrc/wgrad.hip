@@ -10,6 +10,7 @@
 // The pixel range is split over gridDim.y; partial tiles are added to dW with f32 atomics whose 32-lane groups
 // cover 128 contiguous bytes.
 #include "common.h"
+#include <stdlib.h>
 
 struct WgradArgs {
   const void* x;
@@ -19,6 +20,7 @@ struct WgradArgs {
   int x_ld, dy_ld;
   int IH, IW, OH, OW, sy, sx;
   int tiles_k;
+  int tiles, total;      // tiles per pixel split, tiles * splits
   int pix_per_split;     // multiple of BP
   signed char tap_dy[64];
   signed char tap_dx[64];
@@ -58,9 +60,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2][2][BP][LDW];   // [stage][dy|x][pixel][col]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile_k = blockIdx.x % a.tiles_k, tile_n = blockIdx.x / a.tiles_k;
+  // XCD-aware order: hardware deals linear workgroup ids round-robin to the 8 XCDs; give each XCD a contiguous run of
+  // (split, tile) pairs so all tiles of one pixel split — which re-read the same dy / x rows — share one L2.
+  const int per_xcd = gridDim.x >> 3;
+  const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (vid >= a.total) return;
+  const int split = vid / a.tiles, tile = vid - split * a.tiles;
+  const int tile_k = tile % a.tiles_k, tile_n = tile / a.tiles_k;
   const int n0 = tile_n * TILE, k0 = tile_k * TILE;
-  const int m_begin = blockIdx.y * a.pix_per_split;
+  const int m_begin = split * a.pix_per_split;
   const int m_end = min(a.M, m_begin + a.pix_per_split);
   if (m_begin >= m_end) return;
 
@@ -184,9 +192,15 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * OPB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile_k = blockIdx.x % a.tiles_k, tile_n = blockIdx.x / a.tiles_k;
+  // XCD-aware order: hardware deals linear workgroup ids round-robin to the 8 XCDs; give each XCD a contiguous run of
+  // (split, tile) pairs so all tiles of one pixel split — which re-read the same dy / x rows — share one L2.
+  const int per_xcd = gridDim.x >> 3;
+  const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (vid >= a.total) return;
+  const int split = vid / a.tiles, tile = vid - split * a.tiles;
+  const int tile_k = tile % a.tiles_k, tile_n = tile / a.tiles_k;
   const int n0 = tile_n * TILE, k0 = tile_k * TILE;
-  const int m_begin = blockIdx.y * a.pix_per_split;
+  const int m_begin = split * a.pix_per_split;
   const int m_end = min(a.M, m_begin + a.pix_per_split);
   if (m_begin >= m_end) return;
 
@@ -326,17 +340,23 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
       a.tap_dy[r * d->KW + s] = (signed char)(r * d->DH - d->PH);
       a.tap_dx[r * d->KW + s] = (signed char)(s * d->DW - d->PW);
     }
-  const int tile = (a.N > 64 && a.K > 64) ? 128 : 64;
+  static int t64_m = -1;
+  if (t64_m < 0) { const char* e = getenv("SY11_WGRAD_T64_M"); t64_m = e ? atoi(e) : 30000; }
+  const int tile = (a.N > 64 && a.K > 64 && a.M > t64_m) ? 128 : 64;
   a.tiles_k = cdiv(a.K, tile);
   const int tiles = a.tiles_k * cdiv(a.N, tile);
   // enough pixel splits to put ~4 workgroups on each of the 256 CUs, but >= 8 stages (256 pixels) per split
-  int splits = cdiv(1024, tiles);
-  const int max_splits = cdiv(a.M, 256);
+  static int target_wg = -1, min_pix = -1;
+  if (target_wg < 0) { const char* e = getenv("SY11_WGRAD_WG"); target_wg = e ? atoi(e) : 384; }
+  if (min_pix < 0) { const char* e = getenv("SY11_WGRAD_MIN_PIX"); min_pix = e ? atoi(e) : 512; }
+  int splits = cdiv(target_wg, tiles);
+  const int max_splits = cdiv(a.M, min_pix);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   a.pix_per_split = cdiv(cdiv(a.M, splits), 64) * 64;
   splits = cdiv(a.M, a.pix_per_split);
-  dim3 grid(tiles, splits), block(256);
+  a.tiles = tiles; a.total = tiles * splits;
+  dim3 grid(cdiv(a.total, 8) * 8), block(256);
   if (d->dtype == SY11_F32) {
     if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<float, 64>), grid, block, 0, st, a);

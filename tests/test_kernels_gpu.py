@@ -240,7 +240,7 @@ def test_copy_upsample_maxpool(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("B,H,W,heads", [(2, 6, 5, 2), (1, 20, 20, 4), (2, 3, 3, 1)])
+@pytest.mark.parametrize("B,H,W,heads", [(2, 6, 5, 2), (1, 20, 20, 4), (2, 3, 3, 1), (3, 10, 10, 2), (2, 8, 4, 1)])
 def test_attention_fwd_bwd(B, H, W, heads, dtype):
     o = ops()
     kd, hd = 32, 64
