@@ -17,6 +17,7 @@
 // The same kernel computes the data gradient: input := dy, filter := tap-transposed weights, taps := the
 // (P - r*D)/S offsets of one output-parity class, output written with a pixel stride (oy*oy_mul+oy_add).
 #include "common.h"
+#include "tune.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 
   const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 31, fh = lane >> 5;
-  const int nstage = (a.K + BK - 1) / BK;
+  const int nstage = a.debug == 4 ? 0 : (a.K + BK - 1) / BK;   // debug 4 = ablation: epilogue only
   // fragment read addresses (bytes inside a stage), hoisted: one per (tile row set, k-group)
   int fa_off[MI][CPRW / 2], fb_off[NI][CPRW / 2];
 #pragma unroll
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
     }
   }
   __syncthreads();                               // all fragment reads done before the epilogue reuses the ring
+  if (a.debug == 3) return;                      // ablation: no epilogue
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   constexpr bool RT = EPI < 0;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
     for (int idx = tid; idx < BM * cpr; idx += 256) {
       const int rl = idx / cpr, ch = idx - rl * cpr;
       const int m = bm0 + rl, n = bn0 + ch * epc_o;
-      if (m >= a.M || n >= a.N) continue;            // N % epc_o == 0 is guaranteed by the host for this path
+      if (m >= a.M || n >= a.N || a.debug == 5) continue;   // N % epc_o == 0 is guaranteed by the host; debug 5 = tuner dry run
       long obase;
       if (a.dense_out) {
         obase = (long)m * a.y_ld;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = bm0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (m >= a.M) continue;
+        if (m >= a.M || a.debug == 5) continue;
         long obase;
         if (a.dense_out) {
           obase = (long)m * a.y_ld;
@@ -364,47 +366,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// cfg: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x128 (pixels x channels per workgroup)
 template <typename T>
-static int launch_igemm(IgemmArgs& a, hipStream_t st) {
-  int tiles_m = cdiv(a.M, 128);
-  {
-    const long esz = (long)sizeof(T);
-    const long rows_in = (long)(a.M / (a.OH * a.OW)) * a.IH * a.IW;
-    const long xb = ((rows_in - 1) * a.x_ld + a.C) * esz, wb = (long)a.N * a.wK * esz;
-    if (xb >= (1L << 31) || wb >= (1L << 31)) SY11_FAIL(SY11_EUNSUPPORTED, "igemm: operand view larger than 2 GiB (%ld / %ld bytes)", xb, wb);
-    a.x_bytes = (unsigned)xb;
-    a.w_bytes = (unsigned)wb;
-  }
-  {
-    const int osz = (a.flags & SY11_EPI_OUT_F32) ? 4 : (int)sizeof(T);
-    a.vec_out = (((uintptr_t)a.y & 15) == 0) && (((long)a.y_ld * osz) % 16 == 0) && (((long)a.N * osz) % 16 == 0);
-  }
-  int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
-  // small problems (20x20 / 40x40 maps): a 128-wide tile leaves CUs idle, so narrow the tile until the grid fills the chip
-  static int min_wg = -1;
-  if (min_wg < 0) { const char* e = getenv("SY11_IGEMM_MIN_WG"); min_wg = e ? atoi(e) : 512; }
-  while (bn > 32 && (long)tiles_m * cdiv(a.N, bn) < min_wg) bn >>= 1;
+static bool cfg_legal(const IgemmArgs& a, int cfg) {
+  if (cfg != 3) return true;
+  const int epi = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
+                  ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
+  return std::is_same<T, _Float16>::value && (epi == 0 || epi == 1 || epi == 8) && a.N > 64 && a.M >= 256;
+}
+
+template <typename T>
+static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
+  const int bm = cfg == 3 ? 256 : 128;
+  const int bn = cfg == 1 ? 64 : (cfg == 2 ? 32 : 128);
   a.tiles_n = cdiv(a.N, bn);
-  // big layers: a 256-pixel tile (wave tile 128x64) halves the filter traffic per FLOP and the LDS reads per MFMA
-  static int bm256_wg = -1;
-  // off by default: measured slower than 128x128 (r01 sweep) until the k-loop is software-pipelined
-  if (bm256_wg < 0) { const char* e = getenv("SY11_IGEMM_BM256_WG"); bm256_wg = e ? atoi(e) : 0x7fffffff; }
-  const int epi_pre = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
-                      ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
-  const bool bm256 = bn == 128 && std::is_same<T, _Float16>::value && (epi_pre == 0 || epi_pre == 1 || epi_pre == 8) &&
-                     (long)cdiv(a.M, 256) * a.tiles_n >= bm256_wg;
-  if (bm256) tiles_m = cdiv(a.M, 256);
-  const long nwg = (long)tiles_m * a.tiles_n;
+  const long nwg = (long)cdiv(a.M, bm) * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg), block(256);
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("SY11_IGEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-  a.debug = dbg;
   static int variant = -1;                       // SY11_IGEMM_VARIANT: 0 = 128-byte stages x2 (2 WG/CU), 1 = 64-byte stages x2 (4 WG/CU)
   if (variant < 0) { const char* e = getenv("SY11_IGEMM_VARIANT"); variant = e ? atoi(e) : 1; }
   // epilogue specialisation: the common flag sets get branch-free code, anything else the runtime-flag build (EPI = -1)
   int epi = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
             ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
+  const int epi_pre = epi;
   if (sizeof(T) == 2 && !std::is_same<T, _Float16>::value) epi = -1;          // bf16: generic build only
 #define SY11_IGV(BNN, WMM, WNN, EE)                                                                                  \
   do {                                                                                                               \
@@ -423,7 +407,7 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
       default: SY11_IGV(BNN, WMM, WNN, -1); break;               \
     }                                                            \
   } while (0)
-  if (bm256) {
+  if (bm == 256) {
     if constexpr (std::is_same<T, _Float16>::value) {
       if (epi_pre == 0) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 0>), grid, block, 0, st, a);
       else if (epi_pre == 1) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 1>), grid, block, 0, st, a);
@@ -436,6 +420,61 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
 #undef SY11_IG
   SY11_LAUNCH_CHECK("igemm");
   return SY11_OK;
+}
+
+template <typename T>
+static int select_and_launch(IgemmArgs& a, hipStream_t st) {
+  static int dbg = -1, forced = -2;
+  if (dbg < 0) { const char* e = getenv("SY11_IGEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+  if (forced == -2) { const char* e = getenv("SY11_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
+  a.debug = dbg;
+  // static heuristic: widest channel tile the layer fills; small maps (20x20 / 40x40) narrow it until the grid covers the chip
+  int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  while (bn > 32 && (long)cdiv(a.M, 128) * cdiv(a.N, bn) < 512) bn >>= 1;
+  int cfg = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
+  if (forced >= 0 && forced <= 3 && cfg_legal<T>(a, forced)) return launch_cfg<T>(a, st, forced);
+  if (sy11tune::enabled() && dbg == 0) {
+    static sy11tune::Cache cache;
+    const int key[] = {(int)sizeof(T), a.M, a.N, a.K, a.C, a.T, a.sy, a.sx, a.IW, a.OW, a.x_ld, a.y_ld, a.dense_out,
+                       (int)(a.flags & SY11_EPI_OUT_F32)};
+    const uint64_t h = sy11tune::hash(key, (int)(sizeof(key) / sizeof(int)));
+    int hit;
+    if (cache.get(h, &hit)) {
+      if (cfg_legal<T>(a, hit)) cfg = hit;
+    } else if (!sy11tune::capturing(st)) {
+      int cands[4], nc = 0;
+      for (int c = 0; c < 4; ++c) {
+        const int cbn = c == 1 ? 64 : (c == 2 ? 32 : 128);
+        if (cbn > 32 && cbn >= 2 * a.N) continue;                        // tile more than twice the channel count: pure waste
+        if (cfg_legal<T>(a, c)) cands[nc++] = c;
+      }
+      // measuring must leave no trace: no BN statistics; an accumulating epilogue runs with its global stores disabled
+      IgemmArgs t = a;
+      t.stat_sum = t.stat_sq = nullptr;
+      if (t.flags & SY11_EPI_ACCUM) t.debug = 5;
+      const int best = sy11tune::pick(cands, nc, [&](int c) { return launch_cfg<T>(t, st, c); }, st, "igemm", key,
+                                      (int)(sizeof(key) / sizeof(int)));
+      if (best >= 0) { cache.put(h, best); cfg = best; }
+    }
+  }
+  return launch_cfg<T>(a, st, cfg);
+}
+
+template <typename T>
+static int launch_igemm(IgemmArgs& a, hipStream_t st) {
+  {
+    const long esz = (long)sizeof(T);
+    const long rows_in = (long)(a.M / (a.OH * a.OW)) * a.IH * a.IW;
+    const long xb = ((rows_in - 1) * a.x_ld + a.C) * esz, wb = (long)a.N * a.wK * esz;
+    if (xb >= (1L << 31) || wb >= (1L << 31)) SY11_FAIL(SY11_EUNSUPPORTED, "igemm: operand view larger than 2 GiB (%ld / %ld bytes)", xb, wb);
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
+  }
+  {
+    const int osz = (a.flags & SY11_EPI_OUT_F32) ? 4 : (int)sizeof(T);
+    a.vec_out = (((uintptr_t)a.y & 15) == 0) && (((long)a.y_ld * osz) % 16 == 0) && (((long)a.N * osz) % 16 == 0);
+  }
+  return select_and_launch<T>(a, st);
 }
 
 static int validate_conv(const sy11_conv_desc* d, const char* who) {

@@ -1,0 +1,82 @@
+// tune.h — first-call tile-shape selection for the GEMM-shaped kernels (igemm fwd/dgrad, wgrad).
+//
+// The best block tile depends on the layer (pixels vs channels vs reduction length vs how many workgroups the grid
+// gets on 256 CUs) in ways the static heuristics only approximate (r01 sweeps: +-30 % per layer).  The first EAGER call
+// of a given problem times every legal candidate on the caller's stream (2 launches each, HIP events) and caches the
+// winner for the process; calls made while the stream is being captured into a hipGraph never measure — they use the
+// cached pick or fall back to the heuristic, so graph capture stays legal.  SY11_TUNE=0 disables measuring,
+// SY11_TUNE_LOG=1 prints every decision.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
+
+namespace sy11tune {
+
+inline bool enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SY11_TUNE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+inline bool logging() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SY11_TUNE_LOG"); v = (e && e[0] != '0') ? 1 : 0; }
+  return v == 1;
+}
+inline bool capturing(hipStream_t st) {
+  hipStreamCaptureStatus s = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &s) != hipSuccess) { (void)hipGetLastError(); return true; }   // unknown -> do not measure
+  return s != hipStreamCaptureStatusNone;
+}
+inline uint64_t hash(const int* v, int n) {
+  uint64_t h = 1469598103934665603ull;
+  for (int i = 0; i < n; ++i) { h ^= (uint32_t)v[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+struct Cache {
+  std::unordered_map<uint64_t, int> map;
+  std::mutex mu;
+  bool get(uint64_t k, int* out) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = map.find(k);
+    if (it == map.end()) return false;
+    *out = it->second;
+    return true;
+  }
+  void put(uint64_t k, int v) {
+    std::lock_guard<std::mutex> g(mu);
+    map[k] = v;
+  }
+};
+
+// run(cand) launches candidate `cand` on `st` and returns 0 on success.  Returns the fastest candidate, or -1 if
+// nothing could be measured.
+template <class F>
+int pick(const int* cands, int ncand, F&& run, hipStream_t st, const char* what, const int* key, int nkey) {
+  static hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (!e0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) { (void)hipGetLastError(); return -1; }
+  int best = -1;
+  float best_ms = 0.f;
+  for (int i = 0; i < ncand; ++i) {
+    if (run(cands[i]) != 0) continue;                                   // warm-up (code object load, caches)
+    if (hipEventRecord(e0, st) != hipSuccess) return -1;
+    if (run(cands[i]) != 0 || run(cands[i]) != 0) continue;
+    if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+    if (logging()) fprintf(stderr, "[sy11 tune] %s cand %d: %.1f us\n", what, cands[i], ms * 500.f);
+    if (best < 0 || ms < best_ms) { best = cands[i]; best_ms = ms; }
+  }
+  if (logging() && best >= 0) {
+    fprintf(stderr, "[sy11 tune] %s key", what);
+    for (int i = 0; i < nkey; ++i) fprintf(stderr, " %d", key[i]);
+    fprintf(stderr, " -> %d (%.1f us)\n", best, best_ms * 500.f);
+  }
+  return best;
+}
+
+}  // namespace sy11tune

@@ -10,6 +10,7 @@
 // The pixel range is split over gridDim.y; partial tiles are added to dW with f32 atomics whose 32-lane groups
 // cover 128 contiguous bytes.
 #include "common.h"
+#include "tune.h"
 #include <stdlib.h>
 
 struct WgradArgs {
@@ -313,6 +314,35 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
       }
 }
 
+
+// cfg = 3 * (tile == 128) + {0: ~256, 1: ~512, 2: ~1024 workgroups}
+static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
+  const int tile = cfg >= 3 ? 128 : 64;
+  const int target_wg = 256 << (cfg % 3);
+  a.tiles_k = cdiv(a.K, tile);
+  const int tiles = a.tiles_k * cdiv(a.N, tile);
+  int splits = cdiv(target_wg, tiles);
+  const int max_splits = cdiv(a.M, 512);               // >= 8 stages of 64 pixels per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.pix_per_split = cdiv(cdiv(a.M, splits), 64) * 64;
+  splits = cdiv(a.M, a.pix_per_split);
+  a.tiles = tiles; a.total = tiles * splits;
+  dim3 grid(cdiv(a.total, 8) * 8), block(256);
+  if (dtype == SY11_F32) {
+    if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<float, 64>), grid, block, 0, st, a);
+  } else if (dtype == SY11_F16) {
+    if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 128>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wgrad16_kernel<_Float16, 64>), grid, block, 0, st, a);
+  } else {
+    if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<__bf16, 128>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wgrad16_kernel<__bf16, 64>), grid, block, 0, st, a);
+  }
+  SY11_LAUNCH_CHECK("conv2d_wgrad");
+  return SY11_OK;
+}
+
 extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, const void* dy, int dy_ld, float* dw, hipStream_t st);
 extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const void* dy, int32_t dy_ld, float* dw,
                                  void* stream) {
@@ -340,33 +370,37 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
       a.tap_dy[r * d->KW + s] = (signed char)(r * d->DH - d->PH);
       a.tap_dx[r * d->KW + s] = (signed char)(s * d->DW - d->PW);
     }
-  static int t64_m = -1;
-  if (t64_m < 0) { const char* e = getenv("SY11_WGRAD_T64_M"); t64_m = e ? atoi(e) : 30000; }
-  const int tile = (a.N > 64 && a.K > 64 && a.M > t64_m) ? 128 : 64;
-  a.tiles_k = cdiv(a.K, tile);
-  const int tiles = a.tiles_k * cdiv(a.N, tile);
-  // enough pixel splits to put ~4 workgroups on each of the 256 CUs, but >= 8 stages (256 pixels) per split
-  static int target_wg = -1, min_pix = -1;
-  if (target_wg < 0) { const char* e = getenv("SY11_WGRAD_WG"); target_wg = e ? atoi(e) : 384; }
-  if (min_pix < 0) { const char* e = getenv("SY11_WGRAD_MIN_PIX"); min_pix = e ? atoi(e) : 512; }
-  int splits = cdiv(target_wg, tiles);
-  const int max_splits = cdiv(a.M, min_pix);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  a.pix_per_split = cdiv(cdiv(a.M, splits), 64) * 64;
-  splits = cdiv(a.M, a.pix_per_split);
-  a.tiles = tiles; a.total = tiles * splits;
-  dim3 grid(cdiv(a.total, 8) * 8), block(256);
-  if (d->dtype == SY11_F32) {
-    if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<float, 64>), grid, block, 0, st, a);
-  } else if (d->dtype == SY11_F16) {
-    if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 128>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((wgrad16_kernel<_Float16, 64>), grid, block, 0, st, a);
-  } else {
-    if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<__bf16, 128>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((wgrad16_kernel<__bf16, 64>), grid, block, 0, st, a);
+  // static heuristic (r01 sweeps): 128-wide tiles unless the map is small, ~384 workgroups, >= 512 pixels per split
+  int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 3 : 0) + 1;
+  static int forced = -2;
+  if (forced == -2) { const char* e = getenv("SY11_WGRAD_CFG"); forced = e ? atoi(e) : -1; }
+  if (forced >= 0 && forced < 6) return wgrad_launch_cfg(a, d->dtype, st, forced);
+  if (sy11tune::enabled()) {
+    static sy11tune::Cache cache;
+    static float* scratch = nullptr;
+    static size_t scratch_elems = 0;
+    const int key[] = {d->dtype, a.M, a.N, a.K, a.C, a.sy, a.sx, a.IW, a.OW, a.x_ld, a.dy_ld};
+    const uint64_t h = sy11tune::hash(key, (int)(sizeof(key) / sizeof(int)));
+    int hit;
+    if (cache.get(h, &hit)) {
+      cfg = hit;
+    } else if (!sy11tune::capturing(st)) {
+      const size_t need = (size_t)a.N * a.K;
+      if (need > scratch_elems) {                       // candidates accumulate with atomics: measure into a scratch dW
+        if (scratch) (void)hipFree(scratch);
+        scratch = nullptr; scratch_elems = 0;
+        if (hipMalloc((void**)&scratch, need * sizeof(float)) == hipSuccess) scratch_elems = need; else (void)hipGetLastError();
+      }
+      if (scratch) {
+        WgradArgs t = a;
+        t.dw = scratch;
+        const int cands[6] = {0, 1, 2, 3, 4, 5};
+        const int best = sy11tune::pick(cands, 6, [&](int c) { return wgrad_launch_cfg(t, d->dtype, st, c); }, st, "wgrad", key,
+                                        (int)(sizeof(key) / sizeof(int)));
+        if (best >= 0) { cache.put(h, best); cfg = best; }
+      }
+    }
   }
-  SY11_LAUNCH_CHECK("conv2d_wgrad");
-  return SY11_OK;
+  return wgrad_launch_cfg(a, d->dtype, st, cfg);
 }
+

@@ -1,0 +1,56 @@
+"""Time the BatchNorm+SiLU passes (fwd apply, bwd reduce, bwd apply) on every BN'd conv output shape of yolo11s
+(640x640, batch 64, f16) and print achieved HBM bandwidth.   python tools/bn_sweep.py [-v]"""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "spectrogram-yolov11_amd"))
+sys.path.insert(0, str(ROOT / "tools"))
+import torch
+from sy11 import ops
+from conv_sweep import LAYERS
+
+
+def main():
+    verbose = "-v" in sys.argv
+    B, dt, reps = 64, torch.float16, 10
+    tot = {"fwd": 0.0, "reduce": 0.0, "apply": 0.0}
+    byt = {"fwd": 0.0, "reduce": 0.0, "apply": 0.0}
+    shapes = {}
+    for (H, W, C, N, k, s, g, cnt) in LAYERS + [(640, 640, 3, 32, 3, 2, 1, 1)]:
+        OH, OW = ops.conv_out_hw(H, W, k, s, k // 2)
+        shapes[(OH, OW, N)] = shapes.get((OH, OW, N), 0) + cnt
+    for (OH, OW, N), cnt in sorted(shapes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2]):
+        y = torch.randn(B, OH, OW, N, device="cuda", dtype=dt)
+        dz = torch.randn_like(y)
+        z = torch.empty_like(y)
+        dy = torch.empty_like(y)
+        f = lambda *sh: torch.rand(*sh, device="cuda") + 0.5
+        mean, rstd, scale, shift, gamma = f(N), f(N), f(N), f(N), f(N)
+        sg, sgx = torch.zeros(32, N, device="cuda"), torch.zeros(32, N, device="cuda")
+        dgam, dbet = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        fns = {"fwd": (lambda: ops.bn_act_fwd(y, scale, shift, z, True), 2),
+               "reduce": (lambda: ops.bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, True, sg, sgx), 2),
+               "apply": (lambda: ops.bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, True, sg, sgx, dy, dgam, dbet), 3)}
+        row = f"{OH:3d}x{OW:<3d}x{N:<4d} x{cnt:<2d}"
+        for name, (fn, passes) in fns.items():
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            nb = passes * y.numel() * 2
+            tot[name] += ms * cnt
+            byt[name] += nb * cnt
+            row += f"  {name} {ms * 1e3:7.1f} us {nb / ms / 1e9:5.2f} TB/s"
+        if verbose:
+            print(row)
+    print("TOTAL ms/step: " + "  ".join(f"{m} {v:.3f} ({byt[m] / v / 1e9:.2f} TB/s)" for m, v in tot.items()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,8 +1,6 @@
 set -e
-SY11_IGEMM_BM256_WG=1 python -m pytest tests/test_kernels_gpu.py -x -q -k "conv or igemm or dgrad" 2>&1 | tail -3
-run() { echo "$@"; env "$@" python tools/conv_sweep.py fwd,dgrad -v 2>/dev/null > gpurun_out/sw_$N.txt; tail -1 gpurun_out/sw_$N.txt; N=$((N+1)); }
-N=0
-run SY11_IGEMM_BM256_WG=100000000
-run SY11_IGEMM_BM256_WG=512
-run SY11_IGEMM_BM256_WG=256
-run SY11_IGEMM_BM256_WG=128
+python -m pytest tests/test_kernels_gpu.py -x -q 2>&1 | tail -3
+echo "tune off"; SY11_TUNE=0 python tools/conv_sweep.py 2>/dev/null | tail -1
+echo "tune on"; python tools/conv_sweep.py -v 2>/dev/null > gpurun_out/sw_tune.txt; tail -1 gpurun_out/sw_tune.txt
+python bench.py --no-cpu-baseline > gpurun_out/bench_tune.json 2>gpurun_out/bench_tune.err; python -c "
+import json; d=json.load(open('gpurun_out/bench_tune.json')); print(d['value'], d['ms_per_step']); print(d['roofline']['families_ms'])"
