@@ -470,6 +470,206 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, int d
   }
 }
 
+typedef short as16x4_t __attribute__((ext_vector_type(4)));
+// ---- MFMA stem (f16 / bf16, N = 32 or 64, dense NHWC output).  The 27-tap patch is the GEMM reduction (padded to 32):
+// lane (pixel, half) gathers its 16 reduction slots straight from the f32 NCHW image (L1-resident 3x3 neighbourhoods),
+// packs them to 16 bit and feeds v_mfma_f32_32x32x16; the filter sits in registers as the B operand.  The accumulator
+// tile has col = output channel (lane), rows = pixels (registers): BN statistics are in-lane sums + one shuffle, and
+// the tile is transposed through LDS so that the NHWC output leaves in 16-byte coalesced stores.
+typedef short ss16x8 __attribute__((ext_vector_type(8)));
+template <typename T> struct StemMma;
+template <> struct StemMma<_Float16> {
+  static __device__ __forceinline__ f32x16 run(ss16x8 a, ss16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ short bits(float v) { return __builtin_bit_cast(short, (_Float16)v); }
+};
+template <> struct StemMma<__bf16> {
+  static __device__ __forceinline__ f32x16 run(ss16x8 a, ss16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ short bits(float v) { return __builtin_bit_cast(short, (__bf16)v); }
+};
+template <> struct StemMma<float> {
+  static __device__ __forceinline__ f32x16 run(ss16x8, ss16x8, f32x16 c) { return c; }
+  static __device__ __forceinline__ short bits(float) { return 0; }
+};
+
+// reduction slot k = (r*3+s)*3 + c  ->  element offset inside the image of batch b relative to pixel (oy*SH, ox*SW)
+struct StemTap { int off, dy, dx; bool ok; };
+__device__ __forceinline__ StemTap stem_tap(int k, const StemArgs& a) {
+  StemTap t;
+  t.ok = k < 27;
+  const int kk = t.ok ? k : 0;
+  const int rs = kk / 3, c = kk - rs * 3, r = rs / 3, s_ = rs - r * 3;
+  t.dy = r - a.PH;
+  t.dx = s_ - a.PW;
+  t.off = c * a.IH * a.IW + t.dy * a.IW + t.dx;
+  return t;
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a) {
+  constexpr int N = 32 * NT, ROWB = N * 2, ROWS = ROWB + 16, CP = ROWB / 16;
+  __shared__ float red[2][N];
+  __shared__ __attribute__((aligned(16))) unsigned char stage[256 * ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  if (tid < 2 * N) ((float*)red)[tid] = 0.f;
+  ss16x8 wf[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 8 * half + 16 * g + i;
+        wf[nt][g][i] = k < 27 ? StemMma<T>::bits(ElemTraits<T>::to_f(((const T*)a.w)[(nt * 32 + col) * 27 + k])) : (short)0;
+      }
+  StemTap tap[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tap[j] = stem_tap(8 * half + 16 * (j >> 3) + (j & 7), a);
+  const int M = a.B * a.OH * a.OW;
+  const long plane3 = 3L * a.IH * a.IW;
+  const bool silu = a.flags & SY11_EPI_SILU;
+  float s1[NT], s2[NT], bias_v[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { s1[nt] = s2[nt] = 0.f; bias_v[nt] = a.bias ? a.bias[nt * 32 + col] : 0.f; }
+#pragma unroll 1
+  for (int gi = wave * 2; gi < wave * 2 + 2; ++gi) {
+    const int m = blockIdx.x * 256 + gi * 32 + col;
+    const bool ok = m < M;
+    const int mm = ok ? m : M - 1;
+    const int q = mm / a.OW, ox = mm - q * a.OW;
+    const int b = q / a.OH, oy = q - b * a.OH;
+    const int iy0 = oy * a.SH, ix0 = ox * a.SW;
+    const float* xb = a.x + b * plane3 + (long)iy0 * a.IW + ix0;
+    ss16x8 af[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const bool in = ok && tap[j].ok && (unsigned)(iy0 + tap[j].dy) < (unsigned)a.IH && (unsigned)(ix0 + tap[j].dx) < (unsigned)a.IW;
+      const float v = in ? xb[tap[j].off] : 0.f;
+      af[j >> 3][j & 7] = StemMma<T>::bits(v);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      acc = StemMma<T>::run(af[0], wf[nt][0], acc);
+      acc = StemMma<T>::run(af[1], wf[nt][1], acc);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v0 = acc[e];
+        s1[nt] += v0;
+        s2[nt] += v0 * v0;
+        float v = v0 + bias_v[nt];
+        if (silu) v = silu_f(v);
+        const int pl = gi * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        *(T*)(stage + pl * ROWS + (nt * 32 + col) * 2) = ElemTraits<T>::from_f(v);
+      }
+    }
+  }
+  __syncthreads();                                   // red zeroed (top) and stage complete
+  if (a.stat_sum) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float t1 = s1[nt] + __shfl_xor(s1[nt], 32), t2 = s2[nt] + __shfl_xor(s2[nt], 32);
+      if (half == 0) { atomicAdd(&red[0][nt * 32 + col], t1); atomicAdd(&red[1][nt * 32 + col], t2); }
+    }
+  }
+  {
+    unsigned char* yb = (unsigned char*)a.y + (long)blockIdx.x * 256 * ROWB;
+    const int nvalid = min(256, M - (int)blockIdx.x * 256);
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      const int id = i * 256 + tid;
+      const int p = id / CP, cc = id - p * CP;
+      if (p < nvalid) *(uint4*)(yb + (long)id * 16) = *(const uint4*)(stage + p * ROWS + cc * 16);
+    }
+  }
+  if (a.stat_sum) {
+    __syncthreads();
+    if (tid < N) {
+      const long so = (long)(blockIdx.x % a.stat_slots) * N;
+      atomicAdd(a.stat_sum + so + tid, red[0][tid]);
+      atomicAdd(a.stat_sq + so + tid, red[1][tid]);
+    }
+  }
+}
+
+// dW[n][k] += sum_p dy[p][n] * patch[p][k]: pixels are the MFMA reduction.  A = dy^T through the transposing LDS read
+// (32-pixel x N tile per wave, row stride = 64 mod 256 bytes), B = patch column k = lane, gathered from the image.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* dw, int pix_per_block) {
+  constexpr int N = 32 * NT, ROW = (N * 2) % 256 == 64 ? N * 2 : N * 2 + 64, CPR = N / 8;
+  __shared__ __attribute__((aligned(16))) unsigned char sdy[4 * 32 * ROW];
+  __shared__ float sacc[NT][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  for (int i = tid; i < NT * 32 * 33; i += 256) ((float*)sacc)[i] = 0.f;
+  const int M = a.B * a.OH * a.OW;
+  const int m0 = blockIdx.x * pix_per_block, m1 = min(M, m0 + pix_per_block);
+  const StemTap tap = stem_tap(col, a);
+  const long plane3 = 3L * a.IH * a.IW;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+  unsigned char* my = sdy + wave * 32 * ROW;
+  const int trq = (lane & 15) >> 2, trp = lane & 3, trg = (lane >> 4) & 1;
+  const int tr_off = (8 * half + trq) * ROW + (trg * 16 + trp * 4) * 2;
+  const T* dyg = (const T*)a.y;                       // a.y carries dy, a.y_ld its pixel stride
+  for (int c0 = m0; c0 < m1; c0 += 128) {
+    const int p0 = c0 + wave * 32;                    // this wave's 32 pixels
+    __syncthreads();
+    for (int i = lane; i < 32 * CPR; i += 64) {
+      const int pr = i / CPR, ch = i - pr * CPR;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (p0 + pr < m1) v = *(const uint4*)(dyg + (long)(p0 + pr) * a.y_ld + ch * 8);
+      *(uint4*)(my + pr * ROW + ch * 16) = v;
+    }
+    // patch operand: 16 pixels of reduction column `col` for this lane (8*half + 16g + i)
+    ss16x8 bf[2];
+    {
+      const int pw = min(p0, M - 1);
+      const int q = pw / a.OW;
+      int ox = pw - q * a.OW + 8 * half, oy = q % a.OH, b = q / a.OH;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j == 8) ox += 16;                         // slots 8..15 are pixels 16 + 8*half + (0..7)
+        int oxx = ox + (j & 7), oyy = oy, bb = b;
+        while (oxx >= a.OW) { oxx -= a.OW; if (++oyy >= a.OH) { oyy = 0; ++bb; } }
+        const int pj = p0 + 8 * half + 16 * (j >> 3) + (j & 7);
+        const int iy0 = oyy * a.SH, ix0 = oxx * a.SW;
+        const bool in = pj < m1 && tap.ok && (unsigned)(iy0 + tap.dy) < (unsigned)a.IH && (unsigned)(ix0 + tap.dx) < (unsigned)a.IW;
+        const float v = in ? a.x[bb * plane3 + (long)iy0 * a.IW + ix0 + tap.off] : 0.f;
+        bf[j >> 3][j & 7] = StemMma<T>::bits(v);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned char* pa = my + 16 * g * ROW + tr_off + nt * 64;
+        const as16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) as16x4_t*)pa);
+        const as16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) as16x4_t*)(pa + 4 * ROW));
+        const ss16x8 af = ss16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[nt] = StemMma<T>::run(af, bf[g], acc[nt]);
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) atomicAdd(&sacc[nt][(e & 3) + 8 * (e >> 2) + 4 * half][col], acc[nt][e]);
+  __syncthreads();
+  for (int i = tid; i < N * 27; i += 256) {
+    const int n = i / 27, k = i - n * 27;
+    atomicAdd(dw + i, sacc[n >> 5][n & 31][k]);
+  }
+}
+
 static int stem_check(const sy11_conv_desc* d, const char* who) {
   SY11_REQUIRE(d && dtype_ok(d->dtype), "%s: bad desc", who);
   SY11_REQUIRE(d->C == 3 && d->KH == 3 && d->KW == 3 && d->DH == 1 && d->DW == 1 && d->groups == 1, "%s: stem kernel is 3x3, Cin=3, dilation 1", who);
@@ -488,6 +688,15 @@ extern "C" int sy11_stem_conv_fwd(const sy11_conv_desc* d, const float* x_nchw, 
   const long M = (long)d->B * d->OH * d->OW;
   dim3 grid((unsigned)((M + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (d->dtype != SY11_F32 && (d->N == 32 || d->N == 64) && d->y_ld == d->N && ((uintptr_t)y & 15) == 0 &&
+      (long)d->B * 3 * d->IH * d->IW < (1L << 31)) {
+    SY11_DISPATCH_DTYPE(d->dtype, T, {
+      if (d->N == 32) hipLaunchKernelGGL((stem_fwd_mma<T, 1>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((stem_fwd_mma<T, 2>), grid, block, 0, st, a);
+    });
+    SY11_LAUNCH_CHECK("stem_conv_fwd");
+    return SY11_OK;
+  }
   if (d->N <= 16) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 16>), grid, block, 0, st, a)); }
   else if (d->N <= 32) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 32>), grid, block, 0, st, a)); }
   else { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 64>), grid, block, 0, st, a)); }
@@ -508,6 +717,21 @@ extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw
   nblk = (M + ppb - 1) / ppb;
   dim3 grid((unsigned)nblk), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (d->dtype != SY11_F32 && (d->N == 32 || d->N == 64) && dy_ld % 8 == 0 && ((uintptr_t)dy & 15) == 0 &&
+      (long)d->B * 3 * d->IH * d->IW < (1L << 31)) {
+    StemArgs am = a;
+    am.y_ld = dy_ld;
+    long nb = (M + 2047) / 2048;                       // >= 16 chunks of 128 pixels per workgroup, at most 2 workgroups per CU
+    if (nb > 512) nb = 512;
+    const int ppbm = (int)(((M + nb - 1) / nb + 127) / 128 * 128);
+    dim3 gm((unsigned)((M + ppbm - 1) / ppbm));
+    SY11_DISPATCH_DTYPE(d->dtype, T, {
+      if (d->N == 32) hipLaunchKernelGGL((stem_wgrad_mma<T, 1>), gm, block, 0, st, am, dw, ppbm);
+      else hipLaunchKernelGGL((stem_wgrad_mma<T, 2>), gm, block, 0, st, am, dw, ppbm);
+    });
+    SY11_LAUNCH_CHECK("stem_conv_wgrad");
+    return SY11_OK;
+  }
   if (d->N <= 16) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 16>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
   else if (d->N <= 32) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 32>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
   else { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 64>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
