@@ -68,6 +68,26 @@ template <> struct Mma<__bf16> {
   }
 };
 
+// One wave-wide LDS-DMA: 64 lanes x 16 bytes from (buffer descriptor + per-lane byte offset) to LDS at
+// (wave-uniform lds_addr + lane*16); out-of-range offsets deliver zeros.  Issued through inline asm ON PURPOSE: when the
+// compiler sees the LDS-DMA builtin it must assume every later ds_read may alias the DMA destination and puts
+// s_waitcnt vmcnt(0) in front of the MFMA fragment reads and the tap-table reads, i.e. it serialises the copy of stage
+// s+1 behind the math of stage s (r01 ISA inspection).  Here the ring is synchronised by hand (counted vmcnt + s_barrier),
+// and the asm is also never duplicated into divergent branches, so "loads per stage" is an exact count.
+typedef int dma_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, dma_rsrc_t rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ dma_rsrc_t make_dma_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  dma_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32) & 0xffff);    // stride 0, no swizzle
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);                            // num_records (raw buffer: bytes)
+  r[3] = 0x00020000;
+  return r;
+}
+
 // KB = bytes of K per LDS row / stage (128 or 64), NST = LDS ring depth (2 or 3).
 template <int KB> __device__ __forceinline__ int swz(int r) { return KB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
@@ -145,30 +165,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   }
   int kt = (ld_chunk * EPC) / a.C;             // tap of this thread's chunk in the current stage
   int kc = (ld_chunk * EPC) - kt * a.C;        // channel within the tap
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  const dma_rsrc_t xr = make_dma_rsrc(a.x, a.x_bytes), wr_ = make_dma_rsrc(a.w, a.w_bytes);
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bool simple_k = a.C >= BK;
-  const bool b_issue = (BN >= RPP) || (wave * RPI < BN);           // BN < rows-per-pass: only waves covering real rows issue
+  const bool b_issue = (BN >= RPP) || (wave_u * RPI < BN);         // BN < rows-per-pass: only waves covering real rows issue
   __syncthreads();  // tap tables visible
 
-  auto issue_stage = [&](unsigned char* stage_base) {
-    unsigned char* sa = stage_base + wave * (RPI * KB);
-    unsigned char* sb = sa + A_BYTES;
+  auto issue_stage = [&](int stage_idx) {
+    const unsigned sa = smem_base + stage_idx * STAGE + wave_u * (RPI * KB);
+    const unsigned sb = sa + A_BYTES;
     const bool kvalid = kt < a.T;
     const int tt = kvalid ? kt : 0;
     const int xo = s_tapoff[tt] + kc * ESZ, wo = s_tapoff[64 + tt] + kc * ESZ;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const bool ok = kvalid && ((a_mask[i] >> tt) & 1ull);
-      const unsigned off = ok ? (unsigned)(a_off[i] + xo) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(sa + i * (RPP * KB)), 16, off, 0, 0, 0);
+      lds_dma16(sa + i * (RPP * KB), ok ? (unsigned)(a_off[i] + xo) : OOB, xr);
     }
     if (b_issue) {
 #pragma unroll
-      for (int i = 0; i < BPASS; ++i) {
-        const unsigned off = (kvalid && b_off[i] >= 0) ? (unsigned)(b_off[i] + wo) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_, (__attribute__((address_space(3))) void*)(sb + i * (RPP * KB)), 16, off, 0, 0, 0);
-      }
+      for (int i = 0; i < BPASS; ++i) lds_dma16(sb + i * (RPP * KB), (kvalid && b_off[i] >= 0) ? (unsigned)(b_off[i] + wo) : OOB, wr_);
     }
     kc += BK;
     if (simple_k) {                               // C >= BK: at most one tap boundary per stage, branch-free
@@ -223,8 +240,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
         for (int j = 0; j < NI; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
     }
   };
-  issue_stage(smem);
-  if (NST == 3 && nstage > 1) issue_stage(smem + STAGE);
+  if (nstage > 0) issue_stage(0);
+  if (NST == 3 && nstage > 1) issue_stage(1);
   for (int s0 = 0; s0 < nstage; s0 += NST) {
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
@@ -237,8 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (s + NST - 1 < nstage && a.debug != 1) issue_stage(smem + ((u + NST - 1) % NST) * STAGE);
+        if (s + NST - 1 < nstage && a.debug != 1) issue_stage((u + NST - 1) % NST);
         if (a.debug != 2) consume(smem + u * STAGE);
       }
     }

@@ -1,6 +1,2 @@
-set -e
-python -m pytest tests/test_kernels_gpu.py -x -q 2>&1 | tail -3
-echo "tune off"; SY11_TUNE=0 python tools/conv_sweep.py 2>/dev/null | tail -1
-echo "tune on"; python tools/conv_sweep.py -v 2>/dev/null > gpurun_out/sw_tune.txt; tail -1 gpurun_out/sw_tune.txt
-python bench.py --no-cpu-baseline > gpurun_out/bench_tune.json 2>gpurun_out/bench_tune.err; python -c "
-import json; d=json.load(open('gpurun_out/bench_tune.json')); print(d['value'], d['ms_per_step']); print(d['roofline']['families_ms'])"
+for cfg in "64 40 40 384 256 1 1" "64 80 80 128 128 1 1" "64 40 40 64 64 3 1" "64 20 20 128 128 3 1" "64 80 80 256 256 3 2" "64 160 160 32 16 3 1"; do
+for d in 0 1 2 3 4; do echo -n "debug=$d "; SY11_TUNE=0 SY11_IGEMM_DEBUG=$d python tools/conv_micro.py $cfg fwd 50 2>/dev/null; done; done
