@@ -125,6 +125,35 @@ int sy11_upsample2x_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t 
                         void* y, int32_t y_ld, void* stream);
 int sy11_upsample2x_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
                         void* dx, int32_t dx_ld, int32_t accumulate, void* stream);
+/* ---- Fusion('ESChannel') of the fusion model variant (cfg yolo11_fusion_sand3_new.yaml) ----------------------
+ * Replaces Fusion.forward (nn/modules/conv.py:2087-2127) = GCT (conv.py:2284-2301) on the channel concat plus
+ * WeightedSpatialAttention(3) (conv.py:1839-1852) per input:  out = sum_i x_i * (gate[b, i*C + c] + S_i[b, h, w]).
+ * All views NHWC (pointer + pixel stride); C * sizeof(elem) / 16 must be a power of two <= 64 (C = 128 in the model). */
+/* per input: mm[pix] = (mean_c x, max_c x), amax[pix] = first argmax channel, sq[b*sq_ld + c] += sum_hw x^2        */
+int sy11_fusion_stats(int32_t dtype, int32_t B, int32_t HW, int32_t C, const void* x, int32_t x_ld, float* mm,
+                      uint16_t* amax, float* sq, int32_t sq_ld, void* stream);
+/* S = sigmoid(conv3x3(mm; w)), pad 1, no bias; w = cv1.weight[0] in [KH][KW][2] memory (18 floats)                 */
+int sy11_sab_map_fwd(int32_t B, int32_t H, int32_t W, const float* mm, const float* w, float* S, void* stream);
+int sy11_sab_map_bwd(int32_t B, int32_t H, int32_t W, const float* dS, const float* S, const float* mm, const float* w,
+                     float* dmm, float* dw /* [18] accumulated */, void* stream);
+/* gate[b][c] = 1 + tanh(e * gamma / sqrt(mean_c(e^2) + eps) + beta), e = sqrt(sq + eps) * alpha, c in [0, Ct)     */
+int sy11_gct_gate_fwd(int32_t B, int32_t Ct, const float* sq, const float* alpha, const float* gamma, const float* beta,
+                      float eps, float* G, void* stream);
+/* from dG = dL/dgate: q[b][c] with dx += x * q, and dalpha / dgamma / dbeta accumulated over the batch             */
+int sy11_gct_gate_bwd(int32_t B, int32_t Ct, const float* sq, const float* alpha, const float* gamma, const float* beta,
+                      float eps, const float* dG, float* q, float* dalpha, float* dgamma, float* dbeta, void* stream);
+int sy11_fusion_combine(int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t n_in, const void* x0, int32_t ld0,
+                        const float* S0, const void* x1, int32_t ld1, const float* S1, const void* x2, int32_t ld2,
+                        const float* S2, const float* G, void* out, int32_t out_ld, void* stream);
+/* per input: dG[b*dg_ld + c] += sum_pix dout * x ; dS[pix] = sum_c dout * x                                        */
+int sy11_fusion_bwd_reduce(int32_t dtype, int32_t B, int32_t HW, int32_t C, const void* dout, int32_t dout_ld,
+                           const void* x, int32_t x_ld, float* dG, int32_t dg_ld, float* dS, void* stream);
+/* per input: dx (= | +=) dout * (G + S) + x * q + dmm[.,0] / C + [c == amax] dmm[.,1]                              */
+int sy11_fusion_bwd_apply(int32_t dtype, int32_t B, int32_t HW, int32_t C, const void* dout, int32_t dout_ld,
+                          const void* x, int32_t x_ld, const float* G, const float* q, int32_t g_ld, const float* S,
+                          const float* dmm, const uint16_t* amax, void* dx, int32_t dx_ld, int32_t accumulate,
+                          void* stream);
+
 /* nn.MaxPool2d(5, 1, 2) (SPPF, nn/modules/block.py:192,197); idx[m,c] = window position (0..24) of the
  * first maximum in row-major scan order (ATen max_pool2d_with_indices tie rule).                            */
 int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, int32_t x_ld,

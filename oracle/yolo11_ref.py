@@ -15,6 +15,8 @@ Reference lines followed (all under /root/reference/ultralytics):
   nn/tasks.py:161-188 graph walk, :963-1168 channel/depth scaling rules
   utils/tal.py:334-358 make_anchors / dist2bbox        utils/torch_utils.py:238-265 fuse_conv_and_bn
   utils/torch_utils.py:410-420 BN eps=1e-3, momentum=0.03
+  fusion variant (config 5): nn/modules/conv.py:694-710 DDWConv, :1839-1852 WeightedSpatialAttention,
+  :1854-1857,1928-1931,2087-2127 Fusion('ESChannel'), :2284-2301 GCT; nn/tasks.py:1132-1135; cfg yolo11_fusion_sand3_new.yaml
 
 Parity status: PINNED — checked against outputs of the reference itself (tests/golden/*.npz, made by
 oracle/gen_golden.py which imports /root/reference in the dev container).
@@ -59,6 +61,28 @@ GRAPH = (
     ((16, 19, 22), 1, "Detect", ()),
 )
 # [depth, width, max_channels]; "t" is the tiny fixture scale of SURVEY.md appendix A
+# cfg/models/11/yolo11_fusion_sand3_new.yaml:18-57 (backbone = GRAPH[:11]); DDWConv args (c2, k, s, d)
+GRAPH_FUSION = GRAPH[:11] + (
+    (2, 1, "DDWConv", (256, 7, 2, 2)),
+    (4, 1, "Conv", (256, 1, 1)),
+    (4, 1, "DDWConv", (256, 3, 2, 2)),
+    (6, 1, "Conv", (256, 1, 1)),
+    (10, 1, "Conv", (256, 1, 1)),
+    (-1, 1, "Upsample", ()),
+    ((-1, 13, 14), 1, "Fusion", ()),
+    (-1, 2, "C3k2", (256, False)),
+    (-1, 1, "Upsample", ()),
+    ((-1, 11, 12), 1, "Fusion", ()),
+    (-1, 2, "C3k2", (256, False)),
+    (-1, 1, "Conv", (256, 3, 2)),
+    ((-1, 18, 14), 1, "Fusion", ()),
+    (-1, 2, "C3k2", (256, False)),
+    (-1, 1, "Conv", (256, 3, 2)),
+    ((-1, 15), 1, "Fusion", ()),
+    (-1, 2, "C3k2", (256, True)),
+    ((21, 24, 27), 1, "Detect", ()),
+)
+
 SCALES = {"n": (0.50, 0.25, 1024), "s": (0.50, 0.50, 1024), "m": (0.50, 1.00, 512),
           "l": (1.00, 1.00, 512), "x": (1.00, 1.50, 512), "t": (0.50, 0.125, 1024)}
 
@@ -67,20 +91,22 @@ def make_divisible(x, d):  # utils/ops.py:130-143
     return math.ceil(x / d) * d
 
 
-def resolve_graph(scale="s", nc=80, ch=3):
+def resolve_graph(scale="s", nc=80, ch=3, graph=None):
     """Channel / depth arithmetic of parse_model (nn/tasks.py:1085-1101,1136-1141)."""
     depth, width, max_ch = SCALES[scale]
     chans, layers = [], []
-    for i, (f, n, kind, args) in enumerate(GRAPH):
+    for i, (f, n, kind, args) in enumerate(graph or GRAPH):
         n = max(round(n * depth), 1) if n > 1 else n
         c_in = (ch if i == 0 else chans[-1]) if f == -1 else None
         L = {"i": i, "f": f, "kind": kind}
-        if kind in ("Conv", "C3k2", "SPPF", "C2PSA"):
+        if kind in ("Conv", "C3k2", "SPPF", "C2PSA", "DDWConv"):
             c1 = ch if i == 0 else chans[f]
             c2 = make_divisible(min(args[0], max_ch) * width, 8)
             L.update(c1=c1, c2=c2)
             if kind == "Conv":
                 L.update(k=args[1], s=args[2])
+            elif kind == "DDWConv":
+                L.update(k=args[1], s=args[2], d=args[3])
             elif kind == "C3k2":
                 c3k = bool(args[1]) or scale in "mlx"
                 e = args[2] if len(args) > 2 else 0.5
@@ -93,6 +119,8 @@ def resolve_graph(scale="s", nc=80, ch=3):
             c2 = chans[f]
         elif kind == "Concat":
             c2 = sum(chans[x] for x in f)
+        elif kind == "Fusion":                 # tasks.py:1132-1135: always 'ESChannel', output width = first input's
+            c2 = chans[f[0]]
         elif kind == "Detect":
             L.update(nc=nc, ch=[chans[x] for x in f])
             c2 = None
@@ -122,6 +150,33 @@ def conv_bn_act(sd, p, x, k=1, s=1, g=1, d=1, act=True, train=False, fused=False
         if train and (p + "bn.num_batches_tracked") in sd:
             sd[p + "bn.num_batches_tracked"] += 1
     return F.silu(y) if act else y
+
+
+def ddwconv(sd, p, x, k, s, d, train=False, fused=False):
+    """DDWConv.forward (conv.py:694-710): Conv(c1, c2, k, s, g=8, d) then Conv(c2, c2, 1)."""
+    y = conv_bn_act(sd, p + "conv1.", x, k, s, g=8, d=d, train=train, fused=fused)
+    return conv_bn_act(sd, p + "conv2.", y, 1, 1, train=train, fused=fused)
+
+
+def gct(sd, p, x, eps=1e-5):
+    """GCT.forward, mode 'l2' (conv.py:2296-2301)."""
+    alpha, gamma, beta = sd[p + "alpha"], sd[p + "gamma"], sd[p + "beta"]
+    embedding = (x.pow(2).sum((2, 3), keepdim=True) + eps).pow(0.5) * alpha
+    norm = gamma / (embedding.pow(2).mean(dim=1, keepdim=True) + eps).pow(0.5)
+    return x * (1.0 + torch.tanh(embedding * norm + beta))
+
+
+def weighted_spatial_attention(sd, p, x):
+    """WeightedSpatialAttention(3).forward (conv.py:1850-1852)."""
+    m = torch.cat([torch.mean(x, 1, keepdim=True), torch.max(x, 1, keepdim=True)[0]], 1)
+    return x * torch.sigmoid(F.conv2d(m, sd[p + "cv1.weight"], None, 1, 1))
+
+
+def fusion_eschannel(sd, p, xs):
+    """Fusion.forward, 'ESChannel' branch (conv.py:2108-2121): chunks of GCT(cat) plus per-input spatial attention."""
+    a = gct(sd, p + ("gsc2." if len(xs) == 2 else "gsc3."), torch.cat(xs, 1))
+    chunks = torch.chunk(a, len(xs), dim=1)
+    return sum(c + weighted_spatial_attention(sd, p + "sab.", xs[i]) for i, c in enumerate(chunks))
 
 
 def bottleneck(sd, p, x, c1, c2, shortcut, k=(3, 3), e=0.5, train=False, fused=False):
@@ -264,6 +319,10 @@ def forward(sd, layers, x, train=False, fused=False):
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         elif kind == "Concat":
             x = torch.cat(x, 1)
+        elif kind == "DDWConv":
+            x = ddwconv(sd, p, x, L["k"], L["s"], L["d"], train, fused)
+        elif kind == "Fusion":
+            x = fusion_eschannel(sd, p, x)
         elif kind == "Detect":
             maps = detect_head(sd, p, x, L["nc"], train, fused)
             if train:
@@ -364,6 +423,10 @@ def seeded_state_dict(template: dict, seed: int = 0):
             out[k] = 1 + 0.2 * torch.randn(v.shape, generator=g)
         elif k.endswith("bias"):
             out[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif k.endswith(".alpha"):              # GCT parameters (fusion variant): alpha ~ 1, gamma / beta small but alive
+            out[k] = 1 + 0.2 * torch.randn(v.shape, generator=g)
+        elif k.endswith(".gamma") or k.endswith(".beta"):
+            out[k] = 0.3 * torch.randn(v.shape, generator=g)
         else:
             out[k] = torch.randn(v.shape, generator=g) * math.sqrt(2.0 / v[0].numel())
     return out
@@ -408,6 +471,14 @@ def empty_state_dict(layers):
                         bneck(f"{q}m.{t}.", c_, c_, 1.0)
                 else:
                     bneck(q, c, c, 0.5)
+        elif kind == "DDWConv":
+            conv(p + "conv1.", L["c1"], L["c2"], L["k"], g=8)
+            conv(p + "conv2.", L["c2"], L["c2"])
+        elif kind == "Fusion":                  # Fusion(inc_list, 'ESChannel', c1=128): widths hard-coded (conv.py:1855)
+            sd[p + "sab.cv1.weight"] = torch.zeros(1, 2, 3, 3)
+            for nme, mult in (("gsc2.", 2), ("gsc3.", 3)):
+                for q in ("alpha", "gamma", "beta"):
+                    sd[p + nme + q] = torch.zeros(1, 128 * mult, 1, 1)
         elif kind == "SPPF":
             c_ = L["c1"] // 2
             conv(p + "cv1.", L["c1"], c_)

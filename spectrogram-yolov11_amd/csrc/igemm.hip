@@ -39,6 +39,7 @@ struct IgemmArgs {
   int dense_out;          // 1: output offset is m*y_ld (no decode)
   int tiles_n;
   int stat_slots;
+  int stat_stride;        // floats between consecutive stat slots (= channel count of the WHOLE stat row)
   unsigned x_bytes, w_bytes;   // extents of the x / w views in bytes (buffer descriptors range-check against them)
   int debug;              // diagnostic builds only: 1 = skip the LDS-DMA issue after the prologue, 2 = skip the MFMAs
   int vec_out;            // 1: output rows are 16-byte addressable -> LDS-transposed wide stores
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
     }
     __syncthreads();
     if (tid < BN && bn0 + tid < a.N) {
-      const long so = (long)(blockIdx.x % a.stat_slots) * a.N;
+      const long so = (long)(blockIdx.x % a.stat_slots) * a.stat_stride;
       atomicAdd(a.stat_sum + so + bn0 + tid, s_red[tid]);
       atomicAdd(a.stat_sq + so + bn0 + tid, s_red[BN + tid]);
     }
@@ -520,15 +521,43 @@ int sy11_dwconv_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, 
                          float* stat_sum, float* stat_sq, hipStream_t st);
 int sy11_dwconv_dgrad_impl(const sy11_conv_desc* d, const void* dy, int dy_ld, const void* w, void* dx, hipStream_t st);
 
+// grouped convolution (1 < groups < C, e.g. the fusion variant's DDWConv g = 8, conv.py:694-710): every group is an
+// independent dense convolution on a channel slice of x / y (pixel strides unchanged) and a row block of the filter
+static int group_dims(const sy11_conv_desc* d, const char* who, int* cg, int* ng) {
+  SY11_REQUIRE(d->groups > 1 && d->C % d->groups == 0 && d->N % d->groups == 0, "%s: channels not divisible by groups=%d", who, d->groups);
+  *cg = d->C / d->groups;
+  *ng = d->N / d->groups;
+  return SY11_OK;
+}
+
+static int conv2d_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stat_sum,
+                           float* stat_sq, int stat_stride, hipStream_t st);
+
 extern "C" int sy11_conv2d_fwd(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
                                float* stat_sum, float* stat_sq, void* stream) {
   int rc = validate_conv(d, "conv2d_fwd");
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (d->groups != 1) {
-    SY11_REQUIRE(d->groups == d->C && d->C == d->N, "conv2d_fwd: only groups==1 or depthwise (groups==C==N) supported");
-    return sy11_dwconv_fwd_impl(d, x, w, bias, y, stat_sum, stat_sq, st);
+  if (d->groups == 1) return conv2d_fwd_impl(d, x, w, bias, y, stat_sum, stat_sq, d->N, st);
+  if (d->groups == d->C && d->C == d->N) return sy11_dwconv_fwd_impl(d, x, w, bias, y, stat_sum, stat_sq, st);
+  int cg, ng;
+  if ((rc = group_dims(d, "conv2d_fwd", &cg, &ng))) return rc;
+  SY11_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+  const int esz = dtype_size(d->dtype), osz = (d->flags & SY11_EPI_OUT_F32) ? 4 : esz;
+  sy11_conv_desc dg = *d;
+  dg.groups = 1; dg.C = cg; dg.N = ng;
+  for (int g = 0; g < d->groups; ++g) {
+    rc = conv2d_fwd_impl(&dg, (const char*)x + (long)g * cg * esz, (const char*)w + (long)g * ng * d->KH * d->KW * cg * esz,
+                         bias ? bias + g * ng : nullptr, (char*)y + (long)g * ng * osz, stat_sum ? stat_sum + g * ng : nullptr,
+                         stat_sq ? stat_sq + g * ng : nullptr, d->N, st);
+    if (rc) return rc;
   }
+  return SY11_OK;
+}
+
+static int conv2d_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stat_sum,
+                           float* stat_sq, int stat_stride, hipStream_t st) {
+  int rc;
   const int esz = dtype_size(d->dtype);
   if ((rc = check_align(x, d->x_ld, d->C, esz, "conv2d_fwd", "x"))) return rc;
   SY11_REQUIRE(w && y, "conv2d_fwd: null w/y");
@@ -544,6 +573,7 @@ extern "C" int sy11_conv2d_fwd(const sy11_conv_desc* d, const void* x, const voi
   a.OHF = d->OH; a.OWF = d->OW; a.oy_mul = a.ox_mul = 1; a.oy_add = a.ox_add = 0; a.dense_out = 1;
   a.flags = d->flags;
   a.stat_slots = d->stat_slots > 1 ? d->stat_slots : 1;
+  a.stat_stride = stat_stride;
   for (int r = 0; r < d->KH; ++r)
     for (int s = 0; s < d->KW; ++s) {
       const int t = r * d->KW + s;
@@ -559,9 +589,20 @@ extern "C" int sy11_conv2d_dgrad(const sy11_conv_desc* d, const void* dy, int32_
   int rc = validate_conv(d, "conv2d_dgrad");
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (d->groups != 1) {
-    SY11_REQUIRE(d->groups == d->C && d->C == d->N, "conv2d_dgrad: only groups==1 or depthwise supported");
-    return sy11_dwconv_dgrad_impl(d, dy, dy_ld, wt, dx, st);
+  if (d->groups != 1 && d->groups == d->C && d->C == d->N) return sy11_dwconv_dgrad_impl(d, dy, dy_ld, wt, dx, st);
+  if (d->groups != 1) {                 // grouped: wt = [groups][C/g][KH*KW][N/g] (each group's own tap-transposed block)
+    int cg, ng;
+    if ((rc = group_dims(d, "conv2d_dgrad", &cg, &ng))) return rc;
+    SY11_REQUIRE(dy && wt && dx, "conv2d_dgrad: null pointer");
+    const int esz = dtype_size(d->dtype);
+    sy11_conv_desc dg = *d;
+    dg.groups = 1; dg.C = cg; dg.N = ng;
+    for (int g = 0; g < d->groups; ++g) {
+      rc = sy11_conv2d_dgrad(&dg, (const char*)dy + (long)g * ng * esz, dy_ld, (const char*)wt + (long)g * cg * d->KH * d->KW * ng * esz,
+                             (char*)dx + (long)g * cg * esz, stream);
+      if (rc) return rc;
+    }
+    return SY11_OK;
   }
   const int esz = dtype_size(d->dtype);
   SY11_REQUIRE(dy_ld >= d->N, "conv2d_dgrad: dy_ld < N");
@@ -586,6 +627,7 @@ extern "C" int sy11_conv2d_dgrad(const sy11_conv_desc* d, const void* dy, int32_
       a.dense_out = (d->SH == 1 && d->SW == 1);
       a.flags = d->flags & SY11_EPI_ACCUM;
       a.stat_slots = 1;
+      a.stat_stride = a.N;
       int t = 0;
       for (int r = 0; r < d->KH; ++r) {
         const int ny = ph + d->PH - r * d->DH;

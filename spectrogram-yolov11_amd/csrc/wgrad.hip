@@ -349,9 +349,18 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
   SY11_REQUIRE(d && x && dy && dw, "conv2d_wgrad: null argument");
   SY11_REQUIRE(dtype_ok(d->dtype), "conv2d_wgrad: bad dtype");
   hipStream_t st = (hipStream_t)stream;
-  if (d->groups != 1) {
-    SY11_REQUIRE(d->groups == d->C && d->C == d->N, "conv2d_wgrad: only groups==1 or depthwise supported");
-    return sy11_conv2d_wgrad_dw(d, x, dy, dy_ld, dw, st);
+  if (d->groups != 1 && d->groups == d->C && d->C == d->N) return sy11_conv2d_wgrad_dw(d, x, dy, dy_ld, dw, st);
+  if (d->groups != 1) {                 // grouped: independent dense problems on channel slices; dw = [N][KH*KW][C/g]
+    SY11_REQUIRE(d->groups > 1 && d->C % d->groups == 0 && d->N % d->groups == 0, "conv2d_wgrad: channels not divisible by groups=%d", d->groups);
+    const int cg = d->C / d->groups, ng = d->N / d->groups, es = dtype_size(d->dtype);
+    sy11_conv_desc dg = *d;
+    dg.groups = 1; dg.C = cg; dg.N = ng;
+    for (int g = 0; g < d->groups; ++g) {
+      const int rc = sy11_conv2d_wgrad(&dg, (const char*)x + (long)g * cg * es, (const char*)dy + (long)g * ng * es, dy_ld,
+                                       dw + (long)g * ng * d->KH * d->KW * cg, stream);
+      if (rc) return rc;
+    }
+    return SY11_OK;
   }
   const int esz = dtype_size(d->dtype), epc = 16 / esz;
   SY11_REQUIRE(d->KH * d->KW <= 64 && d->KH > 0 && d->KW > 0, "conv2d_wgrad: <=64 taps");

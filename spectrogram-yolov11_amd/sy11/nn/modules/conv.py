@@ -15,7 +15,7 @@ import torch.nn as nn
 from ... import ops
 from ...engine import Act, Ctx, run_module
 
-__all__ = ("Conv", "DWConv", "Concat", "autopad")
+__all__ = ("Conv", "DWConv", "DDWConv", "Concat", "WeightedSpatialAttention", "GCT", "Fusion", "autopad")
 
 
 def autopad(k, p=None, d=1):
@@ -191,12 +191,13 @@ class Conv(nn.Module):
                         ops.conv2d_wgrad(x.data, dy, gs.grad_krsc(conv.weight), k, s, p, d, g)
                 if x.req:
                     gx, acc = x.grad_for_write()
-                    if g == 1:
-                        if s > 1 and k < s and not acc:
+                    if g == 1 or g != C1 or g != N:          # dense, or grouped as `g` dense slices (DDWConv g = 8)
+                        if ops.dgrad_leaves_holes(k, s, p, d) and not acc:
                             gx.zero_()
                             acc = True
-                        ops.conv2d_dgrad(dy, ec.transposed(conv.weight, w), gx, (B, OH, OW, N), k, s, p, d, 1, accumulate=acc)
-                    else:
+                        wtr = ec.transposed(conv.weight, w) if g == 1 else ops.weight_transpose(w, g)
+                        ops.conv2d_dgrad(dy, wtr, gx, (B, OH, OW, N), k, s, p, d, g, accumulate=acc)
+                    else:                                    # depthwise: the kernel reads the filter as stored
                         ops.conv2d_dgrad(dy, w, gx, (B, OH, OW, N), k, s, p, d, g, accumulate=acc)
             ec.tape.append(bw)
         return out
@@ -237,5 +238,119 @@ class Concat(nn.Module):
                     if a.req:
                         g, acc = a.grad_for_write()
                         ops.copy2d(sl.grad_read(), g, accumulate=acc)
+            ec.tape.append(bw)
+        return out
+
+
+class DDWConv(nn.Module):
+    """Fusion-variant down-sampler (conv.py:694-710): grouped (g = 8, optionally dilated) k x k Conv, then a 1x1 Conv.
+    Args (ch_in, ch_out, kernel, stride, dilation, activation)."""
+
+    def __init__(self, c1, c2, k=3, s=2, d=1, act=True):
+        super().__init__()
+        self.conv1 = Conv(c1, c2, k, s, g=8, d=d, act=act)
+        self.kz = k
+        self.conv2 = Conv(c2, c2, k=1, s=1)
+
+    def forward(self, x):
+        return run_module(self, x)[0]
+
+    def _run(self, ec: Ctx, x: Act, out: Act = None) -> Act:
+        return self.conv2._run(ec, self.conv1._run(ec, x), out=out)
+
+
+class WeightedSpatialAttention(nn.Module):
+    """x * sigmoid(conv_k([mean_c x, max_c x])) (conv.py:1839-1852).  Parameter holder for ``cv1`` (2 -> 1, no bias);
+    inside Fusion the 3x3 map is computed by sy11_sab_map_fwd."""
+
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        assert kernel_size in {3, 7}, "kernel size must be 3 or 7"
+        self.cv1 = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+        self.act = nn.Sigmoid()
+
+
+class GCT(nn.Module):
+    """Gated channel transformation (conv.py:2284-2301): x * (1 + tanh(e * gamma / rms_c(e) + beta)), e = ||x||_hw * alpha.
+    Parameter holder; the gate vector is computed by sy11_gct_gate_fwd."""
+
+    def __init__(self, num_channels, epsilon=1e-5, mode="l2", after_relu=False):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(1, num_channels, 1, 1))
+        self.gamma = nn.Parameter(torch.zeros(1, num_channels, 1, 1))
+        self.beta = nn.Parameter(torch.zeros(1, num_channels, 1, 1))
+        self.epsilon = epsilon
+        self.mode = mode
+        self.after_relu = after_relu
+
+
+def _vec(p: torch.Tensor) -> torch.Tensor:
+    """Flat f32 view of a (1, C, 1, 1) parameter (or of its gradient view)."""
+    v = p.detach().reshape(-1)
+    return v if v.dtype == torch.float32 else v.float()
+
+
+class Fusion(nn.Module):
+    """Fusion(inc_list, 'ESChannel', c1=128) (conv.py:1854-1857, 1928-1931, 2087-2127; parse_model forces the
+    'ESChannel' branch, tasks.py:1132-1135):  sum_i [ chunk_i(GCT(cat(x))) + SAB(x_i) ]
+    = sum_i x_i * (gate[b, i*C + c] + S_i[b, h, w]) for 2 or 3 inputs of c1 channels."""
+
+    def __init__(self, inc_list, fusion="bifpn", c1=128):
+        super().__init__()
+        if fusion != "ESChannel":
+            raise ops._lib.Sy11Error(f"Fusion('{fusion}') has no HIP kernel: only the 'ESChannel' branch the model parser selects")
+        self.fusion = fusion
+        self.sab = WeightedSpatialAttention(3)
+        self.gsc2 = GCT(c1 * 2)
+        self.gsc3 = GCT(c1 * 3)
+
+    def forward(self, x):
+        return run_module(self, x)[0]
+
+    def _run(self, ec: Ctx, xs, out: Act = None) -> Act:
+        n = len(xs)
+        if n not in (2, 3):
+            raise ops._lib.Sy11Error("Fusion('ESChannel') takes 2 or 3 inputs")
+        B, H, W, Cn = xs[0].shape
+        gct = self.gsc2 if n == 2 else self.gsc3
+        if gct.alpha.numel() != n * Cn or any(tuple(a.shape) != (B, H, W, Cn) for a in xs):
+            raise ops._lib.Sy11Error(f"Fusion: inputs must all be (B,{gct.alpha.numel() // n},H,W)")
+        dev = ec.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        sq = ec.zeros(B, n * Cn)
+        mm = [torch.empty((B, H, W, 2), **f32) for _ in range(n)]
+        am = [torch.empty((B, H, W), dtype=torch.int16, device=dev) for _ in range(n)]
+        S = [torch.empty((B, H, W), **f32) for _ in range(n)]
+        w18 = ops.filter_krsc(self.sab.cv1.weight.detach()).float().reshape(-1)
+        for i, a in enumerate(xs):
+            ops.fusion_stats(a.data, mm[i], am[i], sq[:, i * Cn:(i + 1) * Cn])
+            ops.sab_map_fwd(mm[i], w18, S[i])
+        alpha, gamma, beta = _vec(gct.alpha), _vec(gct.gamma), _vec(gct.beta)
+        G = torch.empty((B, n * Cn), **f32)
+        ops.gct_gate_fwd(sq, alpha, gamma, beta, gct.epsilon, G)
+        if out is None:
+            out = Act(ec.empty(B, H, W, Cn))
+        ops.fusion_combine([a.data for a in xs], S, G, out.data)
+        if ec.record:
+            def bw():
+                gs = ec.grads
+                dout = out.grad_read()
+                dG = ec.zeros(B, n * Cn)
+                dS = [torch.empty((B, H, W), **f32) for _ in range(n)]
+                dmm = [torch.empty((B, H, W, 2), **f32) for _ in range(n)]
+                has = lambda p: id(p) in gs.views                       # noqa: E731
+                scratch = torch.zeros(18 + 3 * n * Cn, **f32)
+                dw18 = gs.grad_krsc(self.sab.cv1.weight).reshape(-1) if has(self.sab.cv1.weight) else scratch[:18]
+                for i, a in enumerate(xs):
+                    ops.fusion_bwd_reduce(dout, a.data, dG[:, i * Cn:(i + 1) * Cn], dS[i])
+                    ops.sab_map_bwd(dS[i], S[i], mm[i], w18, dmm[i], dw18)
+                q = torch.empty((B, n * Cn), **f32)
+                pg = [gs.grad_vec(p).reshape(-1) if has(p) else scratch[18 + j * n * Cn:18 + (j + 1) * n * Cn]
+                      for j, p in enumerate((gct.alpha, gct.gamma, gct.beta))]
+                ops.gct_gate_bwd(sq, alpha, gamma, beta, gct.epsilon, dG, q, pg[0], pg[1], pg[2])
+                for i, a in enumerate(xs):
+                    if a.req:
+                        g, acc = a.grad_for_write()
+                        ops.fusion_bwd_apply(dout, a.data, G[:, i * Cn:(i + 1) * Cn], q[:, i * Cn:(i + 1) * Cn], S[i], dmm[i], am[i], g, acc)
             ec.tape.append(bw)
         return out

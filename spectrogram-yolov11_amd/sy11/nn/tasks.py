@@ -20,7 +20,7 @@ import yaml
 from .. import ops
 from ..engine import Act, Ctx, run_module
 from ..utils.torch_utils import fuse_conv_and_bn, initialize_weights, intersect_dicts
-from .modules import (C2PSA, C3, SPPF, Bottleneck, C2f, C3k, C3k2, Concat, Conv, Detect, DWConv)
+from .modules import (C2PSA, C3, SPPF, Bottleneck, C2f, C3k, C3k2, Concat, Conv, DDWConv, Detect, DWConv, Fusion)
 
 CFG_DIR = Path(__file__).resolve().parents[1] / "cfg" / "models"
 
@@ -214,6 +214,12 @@ def _graph_strides(model, save):
             return [float(s[j]) for j in f]
         if isinstance(m, Conv):
             s.append(src * m.conv.stride[0])
+        elif isinstance(m, DDWConv):
+            s.append(src * m.conv1.conv.stride[0])
+        elif isinstance(m, Fusion):
+            vals = [prev if j == -1 else s[j] for j in f]
+            assert len(set(vals)) == 1, "Fusion inputs have different strides"
+            s.append(vals[0])
         elif isinstance(m, nn.Upsample):
             s.append(src / float(m.scale_factor))
         elif isinstance(m, Concat):
@@ -226,8 +232,8 @@ def _graph_strides(model, save):
 
 
 _MODULES = {"Conv": Conv, "DWConv": DWConv, "Bottleneck": Bottleneck, "C2f": C2f, "C3": C3, "C3k": C3k, "C3k2": C3k2,
-            "SPPF": SPPF, "C2PSA": C2PSA, "Concat": Concat, "Detect": Detect}
-_BASE = {Conv, DWConv, Bottleneck, C2f, C3, C3k, C3k2, SPPF, C2PSA}
+            "SPPF": SPPF, "C2PSA": C2PSA, "Concat": Concat, "Detect": Detect, "DDWConv": DDWConv, "Fusion": Fusion}
+_BASE = {Conv, DWConv, DDWConv, Bottleneck, C2f, C3, C3k, C3k2, SPPF, C2PSA}
 _REPEAT = {C2f, C3, C3k, C3k2, C2PSA}
 
 
@@ -273,6 +279,10 @@ def parse_model(d, ch, verbose=True):
                     args[3] = True
         elif m is Concat:
             c2 = sum(ch[x] for x in f)
+        elif m is Fusion:                      # tasks.py:1132-1135: the parser overrides the YAML's fusion type
+            args[0] = "ESChannel"
+            c2 = ch[f[0]]
+            args = [[ch[x] for x in f], args[0]]
         elif m is Detect:
             args.append([ch[x] for x in f])
             m.legacy = legacy

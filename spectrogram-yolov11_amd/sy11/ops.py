@@ -54,6 +54,12 @@ def nhwc_empty(B, H, W, Cn, dtype, device):
     return torch.empty((B, H, W, Cn), dtype=dtype, device=device)
 
 
+def dgrad_leaves_holes(k, s, p, d=1) -> bool:
+    """True when some input pixels receive no tap at all (stride > reach, or stride and dilation sharing a factor):
+    sy11_conv2d_dgrad then needs a zeroed dx and SY11_EPI_ACCUM."""
+    return any(all((ph + p - r * d) % s for r in range(k)) for ph in range(s))
+
+
 def conv_out_hw(H, W, k, s, p, d=1):
     return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
@@ -88,8 +94,16 @@ def conv2d_fwd(x, w_krsc, y, k, s=1, p=0, d=1, groups=1, bias=None, stats=None, 
     return y
 
 
-def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:
+def weight_transpose(w_krsc: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """dgrad filter: [C][KH][KW][N] for a dense conv; [groups][C/g][KH][KW][N/g] for a grouped one (each group's block
+    transposed on its own — the layout sy11_conv2d_dgrad documents)."""
     N, KH, KW, Cn = w_krsc.shape
+    if groups > 1:
+        ng = N // groups
+        wt = torch.empty((groups, Cn, KH, KW, ng), dtype=w_krsc.dtype, device=w_krsc.device)
+        for g in range(groups):
+            call("sy11_weight_transpose", dt_code(w_krsc.dtype), ng, KH * KW, Cn, _p(w_krsc[g * ng:(g + 1) * ng]), _p(wt[g]), _stream())
+        return wt
     wt = torch.empty((Cn, KH, KW, N), dtype=w_krsc.dtype, device=w_krsc.device)
     call("sy11_weight_transpose", dt_code(w_krsc.dtype), N, KH * KW, Cn, _p(w_krsc), _p(wt), _stream())
     return wt
@@ -319,3 +333,54 @@ def det_loss_backward(w: DetLossWorkspace, upstream_over_tss: torch.Tensor, gain
     call("sy11_det_loss_bwd", w.B, w.nc, w.nl, cast(w.ptrs), cast(dptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt),
          _p(w.assign), _p(w.norm), _p(upstream_over_tss), float(gains[0]), float(gains[1]), float(gains[2]), _stream())
     return dmaps
+
+
+# ------------------------------------------------------------------------------------------------ Fusion('ESChannel')
+def fusion_stats(x, mm, amax, sq_slice):
+    """x: NHWC view (B,H,W,C); mm (B,H,W,2) f32; amax (B,H,W) int16/uint16; sq_slice: (B, C) view of the (B, n*C) buffer."""
+    _need_gpu(x, mm, amax, sq_slice)
+    B, H, W, Cn = x.shape
+    call("sy11_fusion_stats", dt_code(x.dtype), B, H * W, Cn, _p(x), view_ld(x), _p(mm), _p(amax), _p(sq_slice), sq_slice.stride(0), _stream())
+
+
+def sab_map_fwd(mm, w18, S):
+    B, H, W, _ = mm.shape
+    call("sy11_sab_map_fwd", B, H, W, _p(mm), _p(w18), _p(S), _stream())
+
+
+def sab_map_bwd(dS, S, mm, w18, dmm, dw18):
+    B, H, W, _ = mm.shape
+    call("sy11_sab_map_bwd", B, H, W, _p(dS), _p(S), _p(mm), _p(w18), _p(dmm), _p(dw18), _stream())
+
+
+def gct_gate_fwd(sq, alpha, gamma, beta, eps, G):
+    B, Ct = sq.shape
+    call("sy11_gct_gate_fwd", B, Ct, _p(sq), _p(alpha), _p(gamma), _p(beta), float(eps), _p(G), _stream())
+
+
+def gct_gate_bwd(sq, alpha, gamma, beta, eps, dG, q, dalpha, dgamma, dbeta):
+    B, Ct = sq.shape
+    call("sy11_gct_gate_bwd", B, Ct, _p(sq), _p(alpha), _p(gamma), _p(beta), float(eps), _p(dG), _p(q), _p(dalpha), _p(dgamma),
+         _p(dbeta), _stream())
+
+
+def fusion_combine(xs, Ss, G, out):
+    _need_gpu(*xs, out)
+    B, H, W, Cn = xs[0].shape
+    a = []
+    for i in range(3):
+        a += [_p(xs[i]), view_ld(xs[i]), _p(Ss[i])] if i < len(xs) else [None, 0, None]
+    call("sy11_fusion_combine", dt_code(out.dtype), B, H * W, Cn, len(xs), *a, _p(G), _p(out), view_ld(out), _stream())
+    return out
+
+
+def fusion_bwd_reduce(dout, x, dG_slice, dS):
+    B, H, W, Cn = x.shape
+    call("sy11_fusion_bwd_reduce", dt_code(x.dtype), B, H * W, Cn, _p(dout), view_ld(dout), _p(x), view_ld(x), _p(dG_slice),
+         dG_slice.stride(0), _p(dS), _stream())
+
+
+def fusion_bwd_apply(dout, x, G_slice, q_slice, S, dmm, amax, dx, accumulate):
+    B, H, W, Cn = x.shape
+    call("sy11_fusion_bwd_apply", dt_code(x.dtype), B, H * W, Cn, _p(dout), view_ld(dout), _p(x), view_ld(x), _p(G_slice), _p(q_slice),
+         G_slice.stride(0), _p(S), _p(dmm), _p(amax), _p(dx), view_ld(dx), int(accumulate), _stream())
