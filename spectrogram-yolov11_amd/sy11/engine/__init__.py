@@ -157,7 +157,8 @@ class GradStore:
         self.external_zero = False    # True: the owner (trainer) zeroes ``flat`` itself after each optimizer step
 
     def _build(self, device):
-        total = sum(p.numel() for p in self.params)
+        pad = lambda n: (n + 7) // 8 * 8                  # same 32-byte parameter alignment as engine/flat.py:padded
+        total = sum(pad(p.numel()) for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         off = 0
         for p in self.params:
@@ -169,7 +170,7 @@ class GradStore:
             else:
                 v = seg.view(p.shape)
             self.views[id(p)] = v
-            off += n
+            off += pad(n)
 
     def begin_backward(self, device):
         """Attach views; zero the buffer when the optimizer has cleared the grads (fresh accumulation window)."""

@@ -31,6 +31,13 @@ def param_groups(model):
     return g
 
 
+def padded(n: int) -> int:
+    """Every parameter starts on a 32-byte (f32) / 16-byte (f16 working copy) boundary: the kernels' vector loads need
+    it, and e.g. the fusion variant's 18-element spatial-attention filter would otherwise misalign everything after it.
+    The pad elements are zero in the parameter, gradient and EMA buffers and stay zero under SGD / AdamW."""
+    return (n + 7) // 8 * 8
+
+
 def _view_like(seg: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
     if p.dim() == 4:                                   # conv filter: OIHW shape over [O][KH][KW][I] memory
         o, i, kh, kw = p.shape
@@ -45,8 +52,8 @@ class FlatState:
         groups = param_groups(model)
         self.order = [p for g in groups for p in g]
         dev = self.order[0].device
-        total = sum(p.numel() for p in self.order)
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        total = sum(padded(p.numel()) for p in self.order)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.group_slices = []
         off = 0
         for g in groups:
@@ -56,7 +63,7 @@ class FlatState:
                 v = _view_like(self.flat[off:off + n], p)
                 v.copy_(p.data)
                 p.data = v
-                off += n
+                off += padded(n)
             self.group_slices.append((start, off))
         bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
         nb = sum(b.numel() for b in bufs)
@@ -73,7 +80,7 @@ class FlatState:
         off = 0
         for p in self.order:
             self.offsets[id(p)] = off
-            off += p.numel()
+            off += padded(p.numel())
         self._wt_desc = None
 
     def group_tensors(self, flat: torch.Tensor):

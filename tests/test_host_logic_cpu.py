@@ -207,3 +207,36 @@ def test_nms_wrapper_candidate_selection_matches_reference_rows(monkeypatch):
         assert len(seen) == int(gold[f"{tag}.n"])
         for i, (b, s) in enumerate(seen):
             assert np.array_equal(b.numpy(), gold[f"{tag}.{i}.boxes"]) and np.array_equal(s.numpy(), gold[f"{tag}.{i}.scores"])
+
+
+def test_flat_state_alignment_and_views():
+    """FlatState / GradStore share one padded layout: every parameter starts on an 8-element boundary (the 18-element
+    spatial-attention filter of the fusion variant must not misalign its successors), views alias the flat buffers."""
+    import torch.nn as nn
+    from sy11.engine import GradStore
+    from sy11.engine.flat import FlatState, padded
+    from sy11.nn.modules import Conv, Fusion
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.f = Fusion([128, 128], "ESChannel")
+            self.c = Conv(8, 16, 3)
+    m = Net()
+    ref = {k: v.clone() for k, v in m.state_dict().items()}
+    fs = FlatState(m)
+    assert all(off % 8 == 0 for off in fs.offsets.values())
+    assert fs.flat.numel() == sum(padded(p.numel()) for p in fs.order) > sum(p.numel() for p in fs.order)
+    for k, v in m.state_dict().items():                       # values preserved, parameters now alias the flat buffer
+        assert torch.equal(v, ref[k]), k
+    w = m.f.sab.cv1.weight
+    a = fs.offsets[id(w)]
+    assert w.shape == (1, 2, 3, 3) and torch.equal(fs.flat[a:a + 18].view(1, 3, 3, 2).permute(0, 3, 1, 2), w.data)
+    fs.flat[a] += 1.0
+    assert abs(w.data.flatten()[0].item() - (ref["f.sab.cv1.weight"].flatten()[0].item() + 1.0)) < 1e-6
+    gs = GradStore(m, order=fs.order)
+    gs.begin_backward(torch.device("cpu"))
+    assert gs.flat.numel() == fs.flat.numel()
+    assert gs.grad_vec(m.f.gsc2.alpha).reshape(-1).data_ptr() == gs.views[id(m.f.gsc2.alpha)].data_ptr()   # a view, not a copy
+    for (s0, s1), g in zip(fs.group_slices, fs.group_tensors(gs.flat)):
+        assert g.numel() == s1 - s0
