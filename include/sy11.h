@@ -125,6 +125,10 @@ int sy11_upsample2x_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t 
                         void* y, int32_t y_ld, void* stream);
 int sy11_upsample2x_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
                         void* dx, int32_t dx_ld, int32_t accumulate, void* stream);
+/* pairwise IoU of the validator's _process_batch (utils/metrics.py:52-72; models/yolo/detect/val.py:205-232):
+ * a (n,4), b (m,4) xyxy f32 -> out (n,m) f32, bit-identical to the reference's element-wise evaluation order      */
+int sy11_box_iou(int32_t n, int32_t m, const float* a, const float* b, float eps, float* out, void* stream);
+
 /* ---- Fusion('ESChannel') of the fusion model variant (cfg yolo11_fusion_sand3_new.yaml) ----------------------
  * Replaces Fusion.forward (nn/modules/conv.py:2087-2127) = GCT (conv.py:2284-2301) on the channel concat plus
  * WeightedSpatialAttention(3) (conv.py:1839-1852) per input:  out = sum_i x_i * (gate[b, i*C + c] + S_i[b, h, w]).

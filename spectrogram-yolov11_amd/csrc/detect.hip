@@ -131,3 +131,35 @@ extern "C" int sy11_nms_sorted(int32_t n, const float* boxes, float iou_thres, u
   SY11_LAUNCH_CHECK("nms_sorted");
   return SY11_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ pairwise IoU
+// box_iou of the validator (utils/metrics.py:52-72): out[i][j] = inter / (area_a[i] + area_b[j] - inter + eps), every
+// operation a separate f32 rounding in the reference's order (contraction is off for this file region) so the matrix —
+// and with it the TP assignment at the 10 IoU thresholds — is bit-identical to the ATen element-wise evaluation.
+__global__ __launch_bounds__(256) void box_iou_kernel(int n, int m, const float* __restrict__ a, const float* __restrict__ b, float eps,
+                                                      float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)n * m) return;
+  const int i = (int)(idx / m), j = (int)(idx - (long)i * m);
+  const float ax1 = a[i * 4], ay1 = a[i * 4 + 1], ax2 = a[i * 4 + 2], ay2 = a[i * 4 + 3];
+  const float bx1 = b[j * 4], by1 = b[j * 4 + 1], bx2 = b[j * 4 + 2], by2 = b[j * 4 + 3];
+  // every product goes through an empty asm so the backend cannot fuse it into the following add (-ffp-contract=fast
+  // fuses at instruction selection whatever the source-level pragma says; the reference rounds each step)
+  const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f);
+  const float h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+  float inter = w * h, area_a = (ax2 - ax1) * (ay2 - ay1), area_b = (bx2 - bx1) * (by2 - by1);
+  asm volatile("" : "+v"(inter), "+v"(area_a), "+v"(area_b));
+  out[idx] = inter / (((area_a + area_b) - inter) + eps);
+}
+
+extern "C" int sy11_box_iou(int32_t n, int32_t m, const float* a, const float* b, float eps, float* out, void* stream) {
+  SY11_REQUIRE(n >= 0 && m >= 0, "box_iou: negative count");
+  if (n == 0 || m == 0) return SY11_OK;
+  SY11_REQUIRE(a && b && out, "box_iou: null pointer");
+  const long tot = (long)n * m;
+  hipLaunchKernelGGL(box_iou_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, m, a, b, eps, out);
+  SY11_LAUNCH_CHECK("box_iou");
+  return SY11_OK;
+}

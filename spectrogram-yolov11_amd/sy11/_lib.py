@@ -46,6 +46,7 @@ SIGNATURES = {
     "sy11_copy2d": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
     "sy11_upsample2x_fwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp],
     "sy11_upsample2x_bwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
+    "sy11_box_iou": [_i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "sy11_fusion_stats": [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
     "sy11_sab_map_fwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "sy11_sab_map_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
