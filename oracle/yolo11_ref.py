@@ -432,6 +432,29 @@ def seeded_state_dict(template: dict, seed: int = 0):
     return out
 
 
+def pattern_state_dict(template: dict):
+    """Low-entropy, f16-exact, deterministic values (multiples of 1/8 from a short repeating cycle, per-key rotation):
+    used for the checkpoint fixture so the pickled file compresses to a few KB.  BN variances stay positive."""
+    out = {}
+    cyc = torch.tensor([0.25, -0.125, 0.5, 0.0, -0.375, 0.125, -0.25, 0.375, -0.5])
+    for k, v in template.items():
+        if not v.dtype.is_floating_point or ".dfl." in k:
+            out[k] = v.clone()
+            continue
+        n = v.numel()
+        r = zlib.crc32(k.encode()) % 9
+        base = cyc[(torch.arange(n) + r) % 9].view(v.shape)
+        if k.endswith("running_var"):
+            out[k] = 1.0 + base.abs()
+        elif k.endswith("bn.weight"):
+            out[k] = 1.0 + 0.5 * base
+        elif k.endswith("conv.weight") or k.endswith(".weight"):
+            out[k] = base * (2.0 ** -round(math.log2(max(v[0].numel(), 1)) / 2))      # ~ fan-in scaling, still f16-exact
+        else:
+            out[k] = 0.25 * base
+    return out
+
+
 def seeded_image(shape, seed: int = 5):
     return torch.rand(shape, generator=torch.Generator().manual_seed(seed))
 
