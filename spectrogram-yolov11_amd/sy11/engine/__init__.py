@@ -11,6 +11,8 @@ what the data-parallel step all-reduces (one RCCL call over xGMI instead of per-
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -92,6 +94,18 @@ class Act:
         self._ready = True
 
 
+_SIDE_WGRAD = os.environ.get("SY11_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    d = torch.device(device)
+    key = d.index if d.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=d)
+    return _SIDE_STREAMS[key]
+
+
 class Ctx:
     """State of one forward pass through the engine."""
 
@@ -113,6 +127,29 @@ class Ctx:
         self.wt_views = None          # {id(param): tap-transposed view}, built lazily at the start of backward
         self.w_bank = None
         self.flat_state = None
+        # filter gradients run on a second stream: wgrad(L) only needs dy(L) and the saved input, so it overlaps the
+        # dgrad / BN-backward chain of the layers below it (each kernel alone leaves CUs idle in its prologue / tail)
+        self.side = None
+        self.side_refs: List = []
+        self.use_side = _SIDE_WGRAD and device is not None and torch.device(device).type == "cuda"
+
+    def on_side(self, fn, *keep):
+        """Run ``fn`` (kernel launches) on the side stream, ordered after everything issued so far on the current stream.
+        ``keep``: tensors the side work reads — held until join_side() so the allocator cannot recycle them early."""
+        if not self.use_side:
+            fn()
+            return
+        if self.side is None:
+            self.side = _side_stream(self.device)
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            fn()
+        self.side_refs.append(keep)
+
+    def join_side(self):
+        if self.side is not None and self.side_refs:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self.side_refs.clear()
 
     def attach_flat(self, module):
         """Trainer-provided FlatState: derive all working-dtype filters with one cast (and later one transpose) launch."""
@@ -263,6 +300,7 @@ class EngineFn(torch.autograd.Function):
             a.set_grad(gv)
         for bw in reversed(ec.tape):
             bw()
+        ec.join_side()
         ec.tape.clear()
         ctx.module.__dict__["_sy11_pool_hint"] = ec.pool_need       # next step: one pooled allocation
         gin = []
@@ -324,6 +362,7 @@ class _Graphed:
                         a.set_grad(g)
                 for bw in reversed(ec.tape):
                     bw()
+                ec.join_side()                                      # the wgrad branch joins inside the captured graph
                 self.static_gin = [a.grad_read().permute(0, 3, 1, 2) if a.req else None for a in acts]
             ec.tape.clear()
         torch.cuda.current_stream(dev).wait_stream(side)

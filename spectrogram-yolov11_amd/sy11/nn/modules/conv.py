@@ -185,10 +185,12 @@ class Conv(nn.Module):
                     rg, acc = res.grad_for_write()
                     ops.copy2d(dz, rg, accumulate=acc)
                 if id(conv.weight) in gs.views:
+                    dw = gs.grad_krsc(conv.weight)
                     if stem:
-                        ops.stem_conv_wgrad(x.raw, dy, gs.grad_krsc(conv.weight), s, p)
+                        ec.on_side(lambda: ops.stem_conv_wgrad(x.raw, dy, dw, s, p), x.raw, dy)
                     else:
-                        ops.conv2d_wgrad(x.data, dy, gs.grad_krsc(conv.weight), k, s, p, d, g)
+                        xd = x.data
+                        ec.on_side(lambda: ops.conv2d_wgrad(xd, dy, dw, k, s, p, d, g), xd, dy)
                 if x.req:
                     gx, acc = x.grad_for_write()
                     if g == 1 or g != C1 or g != N:          # dense, or grouped as `g` dense slices (DDWConv g = 8)
