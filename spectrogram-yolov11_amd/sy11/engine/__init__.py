@@ -94,7 +94,9 @@ class Act:
         self._ready = True
 
 
-_SIDE_WGRAD = os.environ.get("SY11_WGRAD_STREAM", "1") != "0"
+# Off by default: measured on MI355X (r01, 3 A/B pairs) the fork/join dependency costs ~10 us per layer inside the captured
+# graph and the overlap does not pay it back (26.55 ms vs 27.05 ms per step) — the kernels already fill every CU.
+_SIDE_WGRAD = os.environ.get("SY11_WGRAD_STREAM", "0") != "0"
 _SIDE_STREAMS = {}
 
 

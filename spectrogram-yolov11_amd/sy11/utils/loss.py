@@ -53,7 +53,7 @@ class _FusedLossFn(torch.autograd.Function):
         from .. import ops as K
         maps = [f.permute(0, 2, 3, 1) for f in feats]
         maps = [m if m.is_contiguous() else m.contiguous() for m in maps]
-        w = K.det_loss_forward(maps, [float(s) for s in crit.stride], crit.nc, gt)
+        w = K.det_loss_forward(maps, crit.stride_f, crit.nc, gt)
         tot = w.sums.sum(0)                                     # [tss, box, cls, dfl]
         tss = tot[0].clamp(min=1.0)
         items = tot[1:4] / tss
@@ -90,6 +90,7 @@ class v8DetectionLoss:
         self.bce = nn.BCEWithLogitsLoss(reduction="none")
         self.hyp = h
         self.stride = m.stride
+        self.stride_f = [float(v) for v in m.stride]   # host copy, read ONCE: float(cuda_tensor[i]) per step is a device sync
         self.nc = m.nc
         self.no = m.nc + m.reg_max * 4
         self.reg_max = m.reg_max
@@ -99,13 +100,30 @@ class v8DetectionLoss:
         self.bbox_loss = BboxLoss(m.reg_max).to(device)
         self.proj = torch.arange(m.reg_max, dtype=torch.float, device=device)
 
-    def preprocess(self, targets, batch_size, scale_tensor):
+    def _max_targets(self, batch_idx, batch_size, counts):
+        """Largest number of targets in one image WITHOUT stalling the launch queue: counted on the host when the labels
+        still live there (the dataloader case); for device labels the value is cached per (storage, version) — the
+        reference's `counts.max()` (utils/loss.py:201) is a device->host read after every forward pass."""
+        if not batch_idx.is_cuda:
+            return int(torch.bincount(batch_idx.long().view(-1), minlength=batch_size).max())
+        key = (batch_idx.data_ptr(), batch_idx._version, batch_idx.numel(), batch_size)
+        cache = self.__dict__.setdefault("_max_gt_cache", {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = int(counts.max())                # one synchronising read, first time this label tensor is seen
+        return cache[key]
+
+    def preprocess(self, targets, batch_size, scale_tensor, batch_idx=None):
         nl, ne = targets.shape
         if nl == 0:
             return torch.zeros(batch_size, 0, ne - 1, device=self.device)
         i = targets[:, 0].long()
-        counts = torch.bincount(i, minlength=batch_size)
-        out = torch.zeros(batch_size, int(counts.max()), ne - 1, device=self.device)
+        # per-image target counts by scatter-add: torch.bincount on a device tensor reads max(i) back to size its output,
+        # i.e. it stalls the host until everything queued so far (the previous step's backward) has finished
+        counts = torch.zeros(batch_size, dtype=torch.long, device=i.device).scatter_add_(0, i, torch.ones_like(i))
+        n_max = self._max_targets(batch_idx, batch_size, counts) if batch_idx is not None else int(counts.max())
+        out = torch.zeros(batch_size, n_max, ne - 1, device=self.device)
         # rank of each target inside its image (stable order), no per-image host loop
         order = torch.argsort(i, stable=True)
         starts = torch.cumsum(counts, 0) - counts
@@ -126,9 +144,13 @@ class v8DetectionLoss:
         feats = preds[1] if isinstance(preds, tuple) else preds
         B = feats[0].shape[0]
         if self.fused and self.reg_max == 16 and all(f.is_cuda and f.dtype == torch.float32 for f in feats):
-            imgsz = torch.tensor(feats[0].shape[2:], dtype=torch.float32) * float(self.stride[0])
+            hw = tuple(feats[0].shape[2:])
+            scales = self.__dict__.setdefault("_scale_cache", {})
+            if hw not in scales:                           # (w, h, w, h) in pixels, uploaded once per input size
+                imgsz = torch.tensor(hw, dtype=torch.float32) * self.stride_f[0]
+                scales[hw] = imgsz[[1, 0, 1, 0]].to(self.device)
             targets = torch.cat((batch["batch_idx"].view(-1, 1), batch["cls"].view(-1, 1), batch["bboxes"]), 1)
-            gt = self.preprocess(targets.to(self.device).float(), B, scale_tensor=imgsz[[1, 0, 1, 0]].to(self.device))
+            gt = self.preprocess(targets.to(self.device).float(), B, scale_tensor=scales[hw], batch_idx=batch["batch_idx"])
             loss, items = _FusedLossFn.apply(self, gt, *feats)
             return loss, items.detach()
         loss = torch.zeros(3, device=self.device)
