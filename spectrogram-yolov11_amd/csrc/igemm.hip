@@ -228,17 +228,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   // NST-deep LDS ring, ONE raw barrier per stage, counted vmcnt; the ring walk is unrolled NST times so every LDS
   // address is (hoisted VGPR + compile-time stage offset).
   auto consume = [&](const unsigned char* st) {
+    constexpr int G = CPRW / 2;
+    if constexpr (BM == 256) {
+      // 2 waves per SIMD only: software-pipeline the fragment reads one k-group ahead of the MFMAs (two register sets)
+      uint4 fa[2][MI], fb[2][NI];
 #pragma unroll
-    for (int g = 0; g < CPRW / 2; ++g) {
-      uint4 fa[MI], fb[NI];
+      for (int i = 0; i < MI; ++i) fa[0][i] = *(const uint4*)(st + fa_off[i][0]);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = *(const uint4*)(st + fa_off[i][g]);
+      for (int j = 0; j < NI; ++j) fb[0][j] = *(const uint4*)(st + fb_off[j][0]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fb[j] = *(const uint4*)(st + fb_off[j][g]);
+      for (int g = 0; g < G; ++g) {
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g + 1 < G) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+          for (int i = 0; i < MI; ++i) fa[nxt][i] = *(const uint4*)(st + fa_off[i][g + 1]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+          for (int j = 0; j < NI; ++j) fb[nxt][j] = *(const uint4*)(st + fb_off[j][g + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) Mma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
+        // pin the order the source states (the machine scheduler otherwise sinks the reads next to their uses to save
+        // registers): all LDS reads of the next group first, then this group's MFMAs
+        if (g + 1 < G) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        uint4 fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *(const uint4*)(st + fa_off[i][g]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[j] = *(const uint4*)(st + fb_off[j][g]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+      }
     }
   };
   if (nstage > 0) issue_stage(0);
@@ -383,9 +411,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-// cfg: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x128 (pixels x channels per workgroup)
+// cfg: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x128 (pixels x channels per workgroup), all with 64-byte K stages;
+// 4..6 = the first three with 128-byte K stages (half the barriers per K, 2 workgroups per CU instead of 4)
+constexpr int IGEMM_NCFG = 7;
 template <typename T>
 static bool cfg_legal(const IgemmArgs& a, int cfg) {
+  if (cfg < 0 || cfg >= IGEMM_NCFG) return false;
+  if (cfg >= 4) return a.K >= 256;                     // long stages only pay with enough K to amortise them
   if (cfg != 3) return true;
   const int epi = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
                   ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
@@ -395,13 +427,13 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
 template <typename T>
 static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
   const int bm = cfg == 3 ? 256 : 128;
-  const int bn = cfg == 1 ? 64 : (cfg == 2 ? 32 : 128);
+  const int tile = cfg >= 4 ? cfg - 4 : cfg;
+  const int bn = tile == 1 ? 64 : (tile == 2 ? 32 : 128);
   a.tiles_n = cdiv(a.N, bn);
   const long nwg = (long)cdiv(a.M, bm) * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg), block(256);
-  static int variant = -1;                       // SY11_IGEMM_VARIANT: 0 = 128-byte stages x2 (2 WG/CU), 1 = 64-byte stages x2 (4 WG/CU)
-  if (variant < 0) { const char* e = getenv("SY11_IGEMM_VARIANT"); variant = e ? atoi(e) : 1; }
+  const int variant = cfg >= 4 ? 0 : 1;          // 0 = 128-byte stages x2 (2 WG/CU), 1 = 64-byte stages x2 (4 WG/CU)
   // epilogue specialisation: the common flag sets get branch-free code, anything else the runtime-flag build (EPI = -1)
   int epi = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
             ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
@@ -449,7 +481,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
   int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   while (bn > 32 && (long)cdiv(a.M, 128) * cdiv(a.N, bn) < 512) bn >>= 1;
   int cfg = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
-  if (forced >= 0 && forced <= 3 && cfg_legal<T>(a, forced)) return launch_cfg<T>(a, st, forced);
+  if (forced >= 0 && cfg_legal<T>(a, forced)) return launch_cfg<T>(a, st, forced);
   if (sy11tune::enabled() && dbg == 0) {
     static sy11tune::Cache cache;
     const int key[] = {(int)sizeof(T), a.M, a.N, a.K, a.C, a.T, a.sy, a.sx, a.IW, a.OW, a.x_ld, a.y_ld, a.dense_out,
@@ -459,9 +491,10 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
     if (cache.get(h, &hit)) {
       if (cfg_legal<T>(a, hit)) cfg = hit;
     } else if (!sy11tune::capturing(st)) {
-      int cands[4], nc = 0;
-      for (int c = 0; c < 4; ++c) {
-        const int cbn = c == 1 ? 64 : (c == 2 ? 32 : 128);
+      int cands[IGEMM_NCFG], nc = 0;
+      for (int c = 0; c < IGEMM_NCFG; ++c) {
+        const int ct = c >= 4 ? c - 4 : c;
+        const int cbn = ct == 1 ? 64 : (ct == 2 ? 32 : 128);
         if (cbn > 32 && cbn >= 2 * a.N) continue;                        // tile more than twice the channel count: pure waste
         if (cfg_legal<T>(a, c)) cands[nc++] = c;
       }
