@@ -246,6 +246,162 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int d
   }
 }
 
+// ---- 3x3 / stride 1 / pad 1 / dilation 1 depthwise (every depthwise layer of the YOLO11 graphs): a thread owns a channel
+// vector and walks RUN consecutive pixels of one image row with a sliding 3x3 window held in registers (16-bit packed):
+// 3 new 16-byte loads per output pixel instead of 9, no integer division in the pixel loop.  One routine serves
+//   MODE 0 forward  (y = sum_t x[p + t - 1] w[t]; BN statistics),
+//   MODE 1 dgrad    (dx = sum_t dy[p + 1 - t] w[t] = the same walk with the taps flipped; optional accumulate),
+//   MODE 2 wgrad    (dw[t] += dy[p] * x[p + t - 1]).
+template <typename T, int VEC> struct PackedVec { typedef T type __attribute__((ext_vector_type(VEC))); };
+
+template <typename T, int VEC, int MODE>
+__global__ __launch_bounds__(256) void dw3x3_kernel(const DwArgs a, int aux_ld, float* dw, int run, int runs_per_row) {
+  typedef typename PackedVec<T, VEC>::type pv;
+  extern __shared__ float red[];                              // MODE 0: [2][C] stats; MODE 2: [9][C] filter gradient
+  const int C = a.C, cpv = a.cpv;
+  const int H = a.IH, W = a.IW;                               // stride 1, pad 1: input and output have the same size
+  const int nred = MODE == 0 ? 2 * C : (MODE == 2 ? 9 * C : 0);
+  for (int i = threadIdx.x; i < nred; i += 256) red[i] = 0.f;
+  if (nred) __syncthreads();
+  const long total = (long)a.B * H * runs_per_row * cpv;
+  float wr[9][VEC];
+  float s1[VEC], s2[VEC], gacc[MODE == 2 ? 9 : 1][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < (MODE == 2 ? 9 : 1); ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) gacc[t][i] = 0.f;
+  int cur_c = -1;
+  const T* src = (const T*)a.x;                               // walked tensor: x (fwd / wgrad) or dy (dgrad)
+  const int src_ld = MODE == 1 ? aux_ld : a.x_ld;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int cv = (int)(gid % cpv);
+    const long rid = gid / cpv;
+    const int rr = (int)(rid % runs_per_row);
+    const long rowid = rid / runs_per_row;
+    const int oy = (int)(rowid % H), b = (int)(rowid / H);
+    const int c = cv * VEC, x0 = rr * run, x1 = min(W, x0 + run);
+    if (MODE != 2 && c != cur_c) {                            // the channel vector is fixed when gridDim.x*256 % cpv == 0
+      float tmp[9][VEC];
+      load_taps<T, VEC, 9>((const T*)a.w, c, 9, tmp);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) wr[t][i] = MODE == 1 ? tmp[8 - t][i] : tmp[t][i];
+      cur_c = c;
+    }
+    const T* rowp[3];
+    bool rok[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy + r - 1;
+      rok[r] = (unsigned)iy < (unsigned)H;
+      rowp[r] = src + ((long)(b * H + (rok[r] ? iy : oy)) * W) * src_ld + c;
+    }
+    pv win[3][3];                                             // [row][column]: columns x-1, x, x+1
+    const pv zero = (pv)(T)0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      win[r][0] = zero;
+      win[r][1] = (rok[r] && x0 - 1 >= 0) ? *(const pv*)(rowp[r] + (long)(x0 - 1) * src_ld) : zero;
+      win[r][2] = rok[r] ? *(const pv*)(rowp[r] + (long)x0 * src_ld) : zero;
+    }
+    for (int x = x0; x < x1; ++x) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        win[r][0] = win[r][1];
+        win[r][1] = win[r][2];
+        win[r][2] = (rok[r] && x + 1 < W) ? *(const pv*)(rowp[r] + (long)(x + 1) * src_ld) : zero;
+      }
+      const long m = (long)(b * H + oy) * W + x;
+      if (MODE == 2) {
+        float g[VEC];
+        dvload<T, VEC>((const T*)a.y + m * aux_ld + c, g);   // a.y = dy
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) gacc[r * 3 + s_][i] += g[i] * ElemTraits<T>::to_f(win[r][s_][i]);
+      } else {
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += ElemTraits<T>::to_f(win[r][s_][i]) * wr[r * 3 + s_][i];
+        T* op = (T*)a.y + m * (MODE == 1 ? a.x_ld : a.y_ld) + c;
+        if (MODE == 0) {
+          const bool silu = a.flags & SY11_EPI_SILU;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            s1[i] += acc[i];
+            s2[i] += acc[i] * acc[i];
+            const float v = acc[i] + (a.bias ? a.bias[c + i] : 0.f);
+            acc[i] = silu ? silu_f(v) : v;
+          }
+        } else if (a.flags & SY11_EPI_ACCUM) {
+          float o[VEC];
+          dvload<T, VEC>(op, o);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += o[i];
+        }
+        dvstore<T, VEC>(op, acc);
+      }
+    }
+  }
+  // the thread's channel vector never changes (gridDim.x * 256 is a multiple of cpv): partial sums stay in registers for
+  // the whole walk and are folded once — LDS atomics per run were 3x the cost of the walk itself
+  const int my_c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpv) * VEC;
+  if (MODE == 0 && a.stat_sum) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { atomicAdd(&red[my_c + i], s1[i]); atomicAdd(&red[C + my_c + i], s2[i]); }
+  }
+  if (MODE == 2) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) atomicAdd(&red[t * C + my_c + i], gacc[t][i]);
+  }
+  if (MODE == 0 && a.stat_sum) {
+    __syncthreads();
+    const long so = (long)(blockIdx.x % a.stat_slots) * C;
+    for (int i = threadIdx.x; i < C; i += 256) {
+      atomicAdd(a.stat_sum + so + i, red[i]);
+      atomicAdd(a.stat_sq + so + i, red[C + i]);
+    }
+  }
+  if (MODE == 2) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * C; e += 256) {          // dw layout [c][t]: consecutive lanes -> consecutive addresses
+      const int ch = e / 9, t = e - ch * 9;
+      atomicAdd(dw + e, red[t * C + ch]);
+    }
+  }
+}
+
+// geometry of the sliding-window kernels: run length such that a row splits evenly-ish, grid such that every thread keeps one
+// channel vector (gridDim.x * 256 a multiple of cpv) and walks >= 2 runs
+static bool dw3x3_ok(const sy11_conv_desc* d, bool vec) {
+  return vec && d->KH == 3 && d->KW == 3 && d->SH == 1 && d->SW == 1 && d->PH == 1 && d->PW == 1 && d->DH == 1 && d->DW == 1 &&
+         d->IH == d->OH && d->IW == d->OW && d->C <= 1536 && 256 % (d->C / (16 / dtype_size(d->dtype))) == 0;
+}
+static void dw3x3_geom(const sy11_conv_desc* d, int cpv, int* run, int* rpr, unsigned* grid, long max_grid = 4096) {
+  const int W = d->IW;
+  int r = W <= 10 ? W : (W % 10 == 0 ? 10 : (W % 8 == 0 ? 8 : 10));
+  *run = r;
+  *rpr = cdiv(W, r);
+  const long total = (long)d->B * d->IH * (*rpr) * cpv;
+  long g = (total + 511) / 512;                               // ~2 runs per thread
+  if (g > max_grid) g = max_grid;
+  if (g < 1) g = 1;
+  *grid = (unsigned)g;
+}
+
 static int dw_setup(const sy11_conv_desc* d, DwArgs& a, bool& vec, const void* p0, int ld0, const void* p1, int ld1, long M,
                     int min_rows_per_thread, dim3& grid) {
   SY11_REQUIRE(d->KH * d->KW <= 9, "depthwise: only up to 9 taps (3x3) are supported");
@@ -278,6 +434,14 @@ int sy11_dwconv_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, 
   int rc = dw_setup(d, a, vec, x, d->x_ld, y, d->y_ld, (long)d->B * d->OH * d->OW, 16, grid);
   if (rc) return rc;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  if (dw3x3_ok(d, vec)) {
+    int run, rpr; unsigned g;
+    dw3x3_geom(d, a.cpv, &run, &rpr, &g, 1024);               // every workgroup ends with 2*C statistic atomics
+    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 0>), dim3(g), dim3(256), 2 * d->C * sizeof(float), st, a, 0,
+                                                         (float*)nullptr, run, rpr));
+    SY11_LAUNCH_CHECK("dwconv_fwd");
+    return SY11_OK;
+  }
   SY11_DISPATCH_DTYPE(d->dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
     if (vec) hipLaunchKernelGGL((dwconv_fwd_kernel<T, VE, 9>), grid, dim3(256), 0, st, a);
@@ -295,6 +459,14 @@ int sy11_dwconv_dgrad_impl(const sy11_conv_desc* d, const void* dy, int dy_ld, c
   int rc = dw_setup(d, a, vec, dy, dy_ld, dx, d->x_ld, (long)d->B * d->IH * d->IW, 16, grid);
   if (rc) return rc;
   a.x = dy; a.w = w; a.y = dx;
+  if (dw3x3_ok(d, vec)) {
+    int run, rpr; unsigned g;
+    dw3x3_geom(d, a.cpv, &run, &rpr, &g);
+    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 1>), dim3(g), dim3(256), 0, st, a, dy_ld, (float*)nullptr,
+                                                         run, rpr));
+    SY11_LAUNCH_CHECK("dwconv_dgrad");
+    return SY11_OK;
+  }
   SY11_DISPATCH_DTYPE(d->dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
     if (vec) hipLaunchKernelGGL((dwconv_dgrad_kernel<T, VE, 9>), grid, dim3(256), 0, st, a, dy_ld);
@@ -312,6 +484,16 @@ extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, cons
   int rc = dw_setup(d, a, vec, x, d->x_ld, dy, dy_ld, (long)d->B * d->OH * d->OW, 32, grid);
   if (rc) return rc;
   a.x = x; a.y = (void*)dy;
+  static int win_wgrad = -1;                                  // r01: the windowed walk wins for fwd / dgrad (148 -> 58 us) but not here
+  if (win_wgrad < 0) { const char* e = getenv("SY11_DW_WINDOW_WGRAD"); win_wgrad = e ? atoi(e) : 0; }
+  if (win_wgrad && dw3x3_ok(d, vec)) {
+    int run, rpr; unsigned g;
+    dw3x3_geom(d, a.cpv, &run, &rpr, &g, 512);                // every workgroup ends with 9*C filter-gradient atomics
+    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 2>), dim3(g), dim3(256), 9 * d->C * sizeof(float), st, a, dy_ld, dw,
+                                                         run, rpr));
+    SY11_LAUNCH_CHECK("dwconv_wgrad");
+    return SY11_OK;
+  }
   SY11_DISPATCH_DTYPE(d->dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
     if (vec) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, VE, 9>), grid, dim3(256), 0, st, a, dy_ld, dw);

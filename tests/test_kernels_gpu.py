@@ -115,7 +115,7 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("Cn,H,W", [(64, 8, 8), (24, 7, 5), (5, 6, 6)])
+@pytest.mark.parametrize("Cn,H,W", [(64, 8, 8), (24, 7, 5), (5, 6, 6), (256, 20, 20), (128, 13, 27), (512, 3, 12)])
 def test_depthwise_conv(Cn, H, W, dtype):
     o = ops()
     B, k, p = 2, 3, 1
