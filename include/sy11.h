@@ -61,6 +61,26 @@ const char* sy11_last_error(void);
 int sy11_conv2d_fwd(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
                     float* stat_sum, float* stat_sq, void* stream);
 
+/* Conv.forward in train mode (conv.py:81: bn(conv(x)) with batch statistics): the convolution above with its BatchNorm
+ * statistics FINALISED in the kernel tail — the last workgroup to finish folds the statistic slots and writes mean / rstd
+ * (saved for backward), scale = gamma*rstd, shift = beta - mean*scale, and the running-stat update, exactly what
+ * sy11_bn_finalize computes.  ticket: zero-initialised int32 words (one per group for grouped convs), returned at zero.   */
+typedef struct sy11_bn_tail {
+  const float* gamma;
+  const float* beta;
+  float* running_mean;         /* both NULL: no running-stat update */
+  float* running_var;
+  float* mean;                 /* outputs, [N] each */
+  float* rstd;
+  float* scale;
+  float* shift;
+  int32_t* ticket;
+  float eps, momentum;
+  double count;                /* pixels per channel: B*OH*OW */
+} sy11_bn_tail;
+int sy11_conv2d_fwd_bn(const sy11_conv_desc* d, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq,
+                       const sy11_bn_tail* bn, void* stream);
+
 /* dx = conv_transpose(dy, w): gradient wrt the input of the conv described by `d`
  * (autograd of nn.Conv2d, fired by loss.backward() at engine/trainer.py:388).
  * `dy` has pixel stride dy_ld, `dx` pixel stride d->x_ld.  wt is the tap-transposed filter made by
@@ -84,6 +104,8 @@ int sy11_weight_transpose_multi(int32_t dtype, int32_t nlayers, int32_t total_ti
 /* first layer: x is the caller's NCHW f32 image (B,3,H,W) in [0,1] (detect/train.py:59 output); y NHWC.    */
 int sy11_stem_conv_fwd(const sy11_conv_desc* d, const float* x_nchw, const void* w, const float* bias, void* y,
                        float* stat_sum, float* stat_sq, void* stream);
+int sy11_stem_conv_fwd_bn(const sy11_conv_desc* d, const float* x_nchw, const void* w, void* y, float* stat_sum,
+                          float* stat_sq, const sy11_bn_tail* bn, void* stream);
 int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw, const void* dy, int32_t dy_ld, float* dw,
                          void* stream);
 

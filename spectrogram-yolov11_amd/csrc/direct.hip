@@ -2,6 +2,7 @@
 // 3-channel stem.  Both are HBM/L2-bound (depthwise: 4.5 FLOP/B; stem: K = 27), so no MFMA: a thread owns a fixed
 // 16-byte channel vector, keeps its filter taps in registers and walks pixels; neighbouring taps are L1/L2 hits.
 #include "common.h"
+#include "bn_tail.h"
 
 template <typename T, int VEC>
 __device__ __forceinline__ void dvload(const T* p, float* f) {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int d
 template <typename T, int VEC> struct PackedVec { typedef T type __attribute__((ext_vector_type(VEC))); };
 
 template <typename T, int VEC, int MODE>
-__global__ __launch_bounds__(256) void dw3x3_kernel(const DwArgs a, int aux_ld, float* dw, int run, int runs_per_row) {
+__global__ __launch_bounds__(256) void dw3x3_kernel(const DwArgs a, int aux_ld, float* dw, int run, int runs_per_row, const BnTailDev tail) {
   typedef typename PackedVec<T, VEC>::type pv;
   extern __shared__ float red[];                              // MODE 0: [2][C] stats; MODE 2: [9][C] filter gradient
   const int C = a.C, cpv = a.cpv;
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const DwArgs a, int aux_ld, 
       atomicAdd(a.stat_sum + so + i, red[i]);
       atomicAdd(a.stat_sq + so + i, red[C + i]);
     }
+    if (tail.ticket) bn_tail_run(tail, a.stat_sum, a.stat_sq, a.stat_slots, C, gridDim.x);
   }
   if (MODE == 2) {
     __syncthreads();
@@ -424,8 +426,29 @@ static int dw_setup(const sy11_conv_desc* d, DwArgs& a, bool& vec, const void* p
   return SY11_OK;
 }
 
+static int dwconv_fwd_tail(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stat_sum, float* stat_sq,
+                           hipStream_t st, const BnTailDev& tail, bool* tail_done);
+
 int sy11_dwconv_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
                          float* stat_sum, float* stat_sq, hipStream_t st) {
+  bool done;
+  return dwconv_fwd_tail(d, x, w, bias, y, stat_sum, stat_sq, st, BnTailDev{}, &done);
+}
+
+// depthwise Conv.forward in train mode: statistics finalised in the kernel tail where the kernel supports it, else by the
+// stand-alone finalize launch right behind it (same stream)
+int sy11_dwconv_fwd_bn_impl(const sy11_conv_desc* d, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq,
+                            const sy11_bn_tail* bn, hipStream_t st) {
+  bool done = false;
+  int rc = dwconv_fwd_tail(d, x, w, nullptr, y, stat_sum, stat_sq, st, bn_tail_dev(bn, d->N, 0, 0), &done);
+  if (rc || done) return rc;
+  return sy11_bn_finalize(d->N, d->stat_slots > 1 ? d->stat_slots : 1, bn->count, stat_sum, stat_sq, bn->gamma, bn->beta, bn->eps, bn->momentum,
+                          bn->running_mean, bn->running_var, bn->mean, bn->rstd, bn->scale, bn->shift, (void*)st);
+}
+
+static int dwconv_fwd_tail(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stat_sum, float* stat_sq,
+                           hipStream_t st, const BnTailDev& tail, bool* tail_done) {
+  *tail_done = false;
   SY11_REQUIRE(x && w && y, "dwconv_fwd: null pointer");
   SY11_REQUIRE(!(d->flags & (SY11_EPI_ACCUM | SY11_EPI_OUT_F32)), "dwconv_fwd: unsupported epilogue flag");
   DwArgs a{};
@@ -438,8 +461,9 @@ int sy11_dwconv_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, 
     int run, rpr; unsigned g;
     dw3x3_geom(d, a.cpv, &run, &rpr, &g, 1024);               // every workgroup ends with 2*C statistic atomics
     SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 0>), dim3(g), dim3(256), 2 * d->C * sizeof(float), st, a, 0,
-                                                         (float*)nullptr, run, rpr));
+                                                         (float*)nullptr, run, rpr, tail));
     SY11_LAUNCH_CHECK("dwconv_fwd");
+    *tail_done = tail.ticket != nullptr && stat_sum != nullptr;
     return SY11_OK;
   }
   SY11_DISPATCH_DTYPE(d->dtype, T, {
@@ -463,7 +487,7 @@ int sy11_dwconv_dgrad_impl(const sy11_conv_desc* d, const void* dy, int dy_ld, c
     int run, rpr; unsigned g;
     dw3x3_geom(d, a.cpv, &run, &rpr, &g);
     SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 1>), dim3(g), dim3(256), 0, st, a, dy_ld, (float*)nullptr,
-                                                         run, rpr));
+                                                         run, rpr, BnTailDev{}));
     SY11_LAUNCH_CHECK("dwconv_dgrad");
     return SY11_OK;
   }
@@ -490,7 +514,7 @@ extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, cons
     int run, rpr; unsigned g;
     dw3x3_geom(d, a.cpv, &run, &rpr, &g, 512);                // every workgroup ends with 9*C filter-gradient atomics
     SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 2>), dim3(g), dim3(256), 9 * d->C * sizeof(float), st, a, dy_ld, dw,
-                                                         run, rpr));
+                                                         run, rpr, BnTailDev{}));
     SY11_LAUNCH_CHECK("dwconv_wgrad");
     return SY11_OK;
   }
@@ -691,7 +715,7 @@ __device__ __forceinline__ StemTap stem_tap(int k, const StemArgs& a) {
 }
 
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a) {
+__global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a, const BnTailDev tail) {
   constexpr int N = 32 * NT, ROWB = N * 2, ROWS = ROWB + 16, CP = ROWB / 16;
   __shared__ float red[2][N];
   __shared__ __attribute__((aligned(16))) unsigned char stage[256 * ROWS];
@@ -776,6 +800,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a) {
       atomicAdd(a.stat_sum + so + tid, red[0][tid]);
       atomicAdd(a.stat_sq + so + tid, red[1][tid]);
     }
+    if (tail.ticket) bn_tail_run(tail, a.stat_sum, a.stat_sq, a.stat_slots, N, gridDim.x);
   }
 }
 
@@ -861,8 +886,29 @@ static int stem_check(const sy11_conv_desc* d, const char* who) {
   return SY11_OK;
 }
 
+static int stem_fwd_tail(const sy11_conv_desc* d, const float* x_nchw, const void* w, const float* bias, void* y, float* stat_sum,
+                         float* stat_sq, void* stream, const BnTailDev& tail, bool* tail_done);
+
 extern "C" int sy11_stem_conv_fwd(const sy11_conv_desc* d, const float* x_nchw, const void* w, const float* bias, void* y,
                                   float* stat_sum, float* stat_sq, void* stream) {
+  bool done;
+  return stem_fwd_tail(d, x_nchw, w, bias, y, stat_sum, stat_sq, stream, BnTailDev{}, &done);
+}
+
+extern "C" int sy11_stem_conv_fwd_bn(const sy11_conv_desc* d, const float* x_nchw, const void* w, void* y, float* stat_sum, float* stat_sq,
+                                     const sy11_bn_tail* bn, void* stream) {
+  SY11_REQUIRE(d && stat_sum && stat_sq && bn && bn->gamma && bn->beta && bn->mean && bn->rstd && bn->scale && bn->shift && bn->ticket &&
+                   bn->count > 0, "stem_conv_fwd_bn: statistics rows and a complete sy11_bn_tail are required");
+  bool done = false;
+  int rc = stem_fwd_tail(d, x_nchw, w, nullptr, y, stat_sum, stat_sq, stream, bn_tail_dev(bn, d->N, 0, 0), &done);
+  if (rc || done) return rc;
+  return sy11_bn_finalize(d->N, d->stat_slots > 1 ? d->stat_slots : 1, bn->count, stat_sum, stat_sq, bn->gamma, bn->beta, bn->eps, bn->momentum,
+                          bn->running_mean, bn->running_var, bn->mean, bn->rstd, bn->scale, bn->shift, stream);
+}
+
+static int stem_fwd_tail(const sy11_conv_desc* d, const float* x_nchw, const void* w, const float* bias, void* y, float* stat_sum,
+                         float* stat_sq, void* stream, const BnTailDev& tail, bool* tail_done) {
+  *tail_done = false;
   int rc = stem_check(d, "stem_conv_fwd");
   if (rc) return rc;
   SY11_REQUIRE(x_nchw && w && y && d->y_ld >= d->N, "stem_conv_fwd: bad argument");
@@ -873,10 +919,11 @@ extern "C" int sy11_stem_conv_fwd(const sy11_conv_desc* d, const float* x_nchw, 
   if (d->dtype != SY11_F32 && (d->N == 32 || d->N == 64) && d->y_ld == d->N && ((uintptr_t)y & 15) == 0 &&
       (long)d->B * 3 * d->IH * d->IW < (1L << 31)) {
     SY11_DISPATCH_DTYPE(d->dtype, T, {
-      if (d->N == 32) hipLaunchKernelGGL((stem_fwd_mma<T, 1>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((stem_fwd_mma<T, 2>), grid, block, 0, st, a);
+      if (d->N == 32) hipLaunchKernelGGL((stem_fwd_mma<T, 1>), grid, block, 0, st, a, tail);
+      else hipLaunchKernelGGL((stem_fwd_mma<T, 2>), grid, block, 0, st, a, tail);
     });
     SY11_LAUNCH_CHECK("stem_conv_fwd");
+    *tail_done = tail.ticket != nullptr && stat_sum != nullptr;
     return SY11_OK;
   }
   if (d->N <= 16) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 16>), grid, block, 0, st, a)); }

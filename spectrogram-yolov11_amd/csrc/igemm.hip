@@ -18,6 +18,7 @@
 // (P - r*D)/S offsets of one output-parity class, output written with a pixel stride (oy*oy_mul+oy_add).
 #include "common.h"
 #include "tune.h"
+#include "bn_tail.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -44,6 +45,7 @@ struct IgemmArgs {
   int debug;              // diagnostic builds only: 1 = skip the LDS-DMA issue after the prologue, 2 = skip the MFMAs
   int vec_out;            // 1: output rows are 16-byte addressable -> LDS-transposed wide stores
   unsigned flags;
+  BnTailDev tail;         // BN statistics finalised by the last workgroup (ticket == nullptr: off)
   signed char tap_dy[64];
   signed char tap_dx[64];
   signed char tap_w[64];
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
       atomicAdd(a.stat_sum + so + bn0 + tid, s_red[tid]);
       atomicAdd(a.stat_sq + so + bn0 + tid, s_red[BN + tid]);
     }
+    if (a.tail.ticket) bn_tail_run(a.tail, a.stat_sum, a.stat_sq, a.stat_slots, a.stat_stride, gridDim.x);
   }
 }
 
@@ -501,6 +504,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
       // measuring must leave no trace: no BN statistics; an accumulating epilogue runs with its global stores disabled
       IgemmArgs t = a;
       t.stat_sum = t.stat_sq = nullptr;
+      t.tail.ticket = nullptr;
       if (t.flags & SY11_EPI_ACCUM) t.debug = 5;
       const int best = sy11tune::pick(cands, nc, [&](int c) { return launch_cfg<T>(t, st, c); }, st, "igemm", key,
                                       (int)(sizeof(key) / sizeof(int)));
@@ -564,7 +568,7 @@ static int group_dims(const sy11_conv_desc* d, const char* who, int* cg, int* ng
 }
 
 static int conv2d_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stat_sum,
-                           float* stat_sq, int stat_stride, hipStream_t st);
+                           float* stat_sq, int stat_stride, hipStream_t st, const BnTailDev& tail = BnTailDev{});
 
 extern "C" int sy11_conv2d_fwd(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
                                float* stat_sum, float* stat_sq, void* stream) {
@@ -588,8 +592,35 @@ extern "C" int sy11_conv2d_fwd(const sy11_conv_desc* d, const void* x, const voi
   return SY11_OK;
 }
 
+int sy11_dwconv_fwd_bn_impl(const sy11_conv_desc* d, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq,
+                            const sy11_bn_tail* bn, hipStream_t st);
+
+extern "C" int sy11_conv2d_fwd_bn(const sy11_conv_desc* d, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq,
+                                  const sy11_bn_tail* bn, void* stream) {
+  int rc = validate_conv(d, "conv2d_fwd_bn");
+  if (rc) return rc;
+  SY11_REQUIRE(stat_sum && stat_sq && bn && bn->gamma && bn->beta && bn->mean && bn->rstd && bn->scale && bn->shift && bn->ticket &&
+                   bn->count > 0, "conv2d_fwd_bn: statistics rows and a complete sy11_bn_tail are required");
+  SY11_REQUIRE((bn->running_mean == nullptr) == (bn->running_var == nullptr), "conv2d_fwd_bn: running stats must both be given or both NULL");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->groups == 1) return conv2d_fwd_impl(d, x, w, nullptr, y, stat_sum, stat_sq, d->N, st, bn_tail_dev(bn, d->N, 0, 0));
+  if (d->groups == d->C && d->C == d->N) return sy11_dwconv_fwd_bn_impl(d, x, w, y, stat_sum, stat_sq, bn, st);
+  int cg, ng;
+  if ((rc = group_dims(d, "conv2d_fwd_bn", &cg, &ng))) return rc;
+  SY11_REQUIRE(x && w && y, "conv2d_fwd_bn: null pointer");
+  const int esz = dtype_size(d->dtype);
+  sy11_conv_desc dg = *d;
+  dg.groups = 1; dg.C = cg; dg.N = ng;
+  for (int g = 0; g < d->groups; ++g) {
+    rc = conv2d_fwd_impl(&dg, (const char*)x + (long)g * cg * esz, (const char*)w + (long)g * ng * d->KH * d->KW * cg * esz, nullptr,
+                         (char*)y + (long)g * ng * esz, stat_sum + g * ng, stat_sq + g * ng, d->N, st, bn_tail_dev(bn, ng, g * ng, g));
+    if (rc) return rc;
+  }
+  return SY11_OK;
+}
+
 static int conv2d_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stat_sum,
-                           float* stat_sq, int stat_stride, hipStream_t st) {
+                           float* stat_sq, int stat_stride, hipStream_t st, const BnTailDev& tail) {
   int rc;
   const int esz = dtype_size(d->dtype);
   if ((rc = check_align(x, d->x_ld, d->C, esz, "conv2d_fwd", "x"))) return rc;
@@ -607,6 +638,7 @@ static int conv2d_fwd_impl(const sy11_conv_desc* d, const void* x, const void* w
   a.flags = d->flags;
   a.stat_slots = d->stat_slots > 1 ? d->stat_slots : 1;
   a.stat_stride = stat_stride;
+  a.tail = tail;
   for (int r = 0; r < d->KH; ++r)
     for (int s = 0; s < d->KW; ++s) {
       const int t = r * d->KW + s;

@@ -26,12 +26,21 @@ class ConvDesc(C.Structure):
         "KH", "KW", "SH", "SW", "PH", "PW", "DH", "DW", "groups")] + [("flags", C.c_uint32), ("stat_slots", C.c_int32)]
 
 
+class BnTail(C.Structure):
+    """sy11_bn_tail: BatchNorm finalisation folded into the producing conv's tail (include/sy11.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("gamma", "beta", "running_mean", "running_var", "mean", "rstd", "scale", "shift", "ticket")] \
+        + [("eps", C.c_float), ("momentum", C.c_float), ("count", C.c_double)]
+
+
 _vp, _i32, _i64, _f32, _f64, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32
 _dp = C.POINTER(ConvDesc)
+_bp = C.POINTER(BnTail)
 
 # name -> argtypes (restype is int unless noted); the single source the symbol-export test checks against sy11.h
 SIGNATURES = {
     "sy11_conv2d_fwd": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sy11_conv2d_fwd_bn": [_dp, _vp, _vp, _vp, _vp, _vp, _bp, _vp],
+    "sy11_stem_conv_fwd_bn": [_dp, _vp, _vp, _vp, _vp, _vp, _bp, _vp],
     "sy11_conv2d_dgrad": [_dp, _vp, _i32, _vp, _vp, _vp],
     "sy11_conv2d_wgrad": [_dp, _vp, _vp, _i32, _vp, _vp],
     "sy11_weight_transpose": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],

@@ -15,6 +15,10 @@ import torch.nn as nn
 from ... import ops
 from ...engine import Act, Ctx, run_module
 
+import os
+
+_BN_TAIL = os.environ.get("SY11_BN_TAIL", "0") != "0"
+
 __all__ = ("Conv", "DWConv", "DDWConv", "Concat", "WeightedSpatialAttention", "GCT", "Fusion", "autopad")
 
 
@@ -157,17 +161,27 @@ class Conv(nn.Module):
             return out
         slots = 32 if B * OH * OW >= 128 * 64 else 1        # spread the per-channel stat atomics (see sy11.h)
         st = ec.zeros(2, slots, N)
-        if stem:
-            ops.stem_conv_fwd(x.raw, w, y, s, p, stats=(st[0], st[1]))
-        else:
-            ops.conv2d_fwd(x.data, w, y, k, s, p, d, g, stats=(st[0], st[1]))
         v = torch.empty((4, N), dtype=torch.float32, device=ec.device)
         mean, rstd, scale, shift = v[0], v[1], v[2], v[3]
         gamma, beta = bn.weight.detach().float(), bn.bias.detach().float()
         mom = 0.1 if bn.momentum is None else bn.momentum
         track = bn.track_running_stats and bn.running_mean is not None
-        ops.bn_finalize(B * OH * OW, st[0], st[1], gamma, beta, bn.eps, mom, bn.running_mean if track else None,
-                        bn.running_var if track else None, mean, rstd, scale, shift)
+        rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+        if _BN_TAIL:
+            # conv + batch statistics + their finalisation in ONE launch (the last workgroup folds the statistic slots,
+            # csrc/bn_tail.h).  Measured r01: 27.7 ms/step vs 26.4 with the separate 5 us finalize kernel — a single workgroup
+            # folding 32 slots x C through device-scope loads is slower than C/32 workgroups doing it in parallel.  Off by default.
+            tail = (B * OH * OW, gamma, beta, bn.eps, mom, rm, rv, mean, rstd, scale, shift, ec.zeros(max(g, 1)))
+            if stem:
+                ops.stem_conv_fwd_bn(x.raw, w, y, s, p, (st[0], st[1]), tail)
+            else:
+                ops.conv2d_fwd_bn(x.data, w, y, k, s, p, d, g, (st[0], st[1]), tail)
+        else:
+            if stem:
+                ops.stem_conv_fwd(x.raw, w, y, s, p, stats=(st[0], st[1]))
+            else:
+                ops.conv2d_fwd(x.data, w, y, k, s, p, d, g, stats=(st[0], st[1]))
+            ops.bn_finalize(B * OH * OW, st[0], st[1], gamma, beta, bn.eps, mom, rm, rv, mean, rstd, scale, shift)
         if track and bn.num_batches_tracked is not None:
             ec.bn_counters.append(bn.num_batches_tracked)
         ops.bn_act_fwd(y, scale, shift, out.data, silu=silu, res=res.data if res is not None else None)

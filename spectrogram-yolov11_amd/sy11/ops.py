@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import EPI_ACCUM, EPI_OUT_F32, EPI_SILU, ConvDesc, call
+from ._lib import EPI_ACCUM, EPI_OUT_F32, EPI_SILU, BnTail, ConvDesc, call
 
 _DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
 
@@ -91,6 +91,35 @@ def conv2d_fwd(x, w_krsc, y, k, s=1, p=0, d=1, groups=1, bias=None, stats=None, 
     dsc = _desc(x.shape, view_ld(x), y.shape, view_ld(y), x.dtype, k, s, p, d, groups, flags, slots)
     call("sy11_conv2d_fwd", C.byref(dsc), _p(x), _p(w_krsc), _p(bias), _p(y), _p(stats[0]) if stats else None,
          _p(stats[1]) if stats else None, _stream())
+    return y
+
+
+def _bn_tail(count, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, ticket):
+    return BnTail(_p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift), _p(ticket),
+                  float(eps), float(momentum), float(count))
+
+
+def conv2d_fwd_bn(x, w_krsc, y, k, s, p, d, groups, stats, bn):
+    """Train-mode Conv.forward up to the BN statistics: conv + per-channel sum/sumsq + (in the kernel tail) mean / rstd /
+    scale / shift / running-stat update.  ``bn`` = (count, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd,
+    scale, shift, ticket) with ``ticket`` a zeroed 4-byte-per-group buffer."""
+    _need_gpu(x, w_krsc, y)
+    slots = stats[0].shape[0] if stats[0].dim() == 2 else 1
+    dsc = _desc(x.shape, view_ld(x), y.shape, view_ld(y), x.dtype, k, s, p, d, groups, 0, slots)
+    tail = _bn_tail(*bn)
+    call("sy11_conv2d_fwd_bn", C.byref(dsc), _p(x), _p(w_krsc), _p(y), _p(stats[0]), _p(stats[1]), C.byref(tail), _stream())
+    return y
+
+
+def stem_conv_fwd_bn(x_nchw, w_krsc, y, s, p, stats, bn):
+    _need_gpu(x_nchw, w_krsc, y)
+    if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or x_nchw.shape[1] != 3:
+        raise _lib.Sy11Error("stem_conv_fwd_bn: x must be a contiguous NCHW f32 image with 3 channels")
+    B, _, IH, IW = x_nchw.shape
+    slots = stats[0].shape[0] if stats[0].dim() == 2 else 1
+    dsc = _desc((B, IH, IW, 3), 3, y.shape, view_ld(y), y.dtype, 3, s, p, 1, 1, 0, slots)
+    tail = _bn_tail(*bn)
+    call("sy11_stem_conv_fwd_bn", C.byref(dsc), _p(x_nchw), _p(w_krsc), _p(y), _p(stats[0]), _p(stats[1]), C.byref(tail), _stream())
     return y
 
 

@@ -317,3 +317,44 @@ def test_stft_logmel_matches_oracle():
     assert img.shape == (2, 3, 640, 640)
     assert (img - ref_img).abs().max().item() < 2e-3
     assert img.min().item() == 0.0 and abs(img.max().item() - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["dense", "grouped", "depthwise", "stem"])
+def test_conv_fwd_bn_tail_matches_separate_finalize(case):
+    """sy11_conv2d_fwd_bn / sy11_stem_conv_fwd_bn (statistics finalised by the last workgroup) == conv + sy11_bn_finalize."""
+    o = ops()
+    dtype = torch.float16
+    B, H, W = 3, 20, 20
+    Cn, N, k, s, p, g = {"dense": (32, 64, 3, 1, 1, 1), "grouped": (64, 32, 3, 2, 1, 8), "depthwise": (64, 64, 3, 1, 1, 64),
+                         "stem": (3, 32, 3, 2, 1, 1)}[case]
+    OH, OW = o.conv_out_hw(H, W, k, s, p)
+    torch.manual_seed(0)
+    w = (torch.randn(N, k, k, Cn // g, device=DEV) * 0.2).to(dtype)
+    gamma, beta = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV) * 0.1
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+        st = torch.zeros(2, 32, N, device=DEV)
+        v = torch.empty(4, N, device=DEV)
+        y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
+        if case == "stem":
+            x = torch.rand(B, 3, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+        else:
+            x = torch.randn(B, H, W, Cn, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).to(dtype)
+        tail = (B * OH * OW, gamma, beta, 1e-3, 0.03, rm, rv, v[0], v[1], v[2], v[3], torch.zeros(max(g, 1), device=DEV))
+        if fused:
+            if case == "stem":
+                o.stem_conv_fwd_bn(x, w, y, s, p, (st[0], st[1]), tail)
+            else:
+                o.conv2d_fwd_bn(x, w, y, k, s, p, 1, g, (st[0], st[1]), tail)
+            assert float(tail[-1].abs().sum()) == 0.0                 # tickets returned at zero
+        else:
+            if case == "stem":
+                o.stem_conv_fwd(x, w, y, s, p, stats=(st[0], st[1]))
+            else:
+                o.conv2d_fwd(x, w, y, k, s, p, 1, g, stats=(st[0], st[1]))
+            o.bn_finalize(B * OH * OW, st[0], st[1], gamma, beta, 1e-3, 0.03, rm, rv, v[0], v[1], v[2], v[3])
+        outs.append((y.float().cpu(), v.cpu(), rm.cpu(), rv.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b_ in zip(outs[0][1:], outs[1][1:]):
+        assert torch.allclose(a, b_, rtol=1e-5, atol=1e-6)
