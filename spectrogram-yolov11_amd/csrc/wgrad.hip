@@ -21,6 +21,8 @@ struct WgradArgs {
   int x_ld, dy_ld;
   int IH, IW, OH, OW, sy, sx;
   int tiles_k;
+  unsigned x_bytes, dy_bytes;   // extents of the x / dy views (buffer descriptors: out-of-range offset = zero fill)
+  unsigned mag_ow, mag_oh;      // ceil(2^20 / OW), ceil(2^20 / OH): exact quotients for the small ranges of the pixel walk
   int tiles, total;      // tiles per pixel split, tiles * splits
   int pix_per_split;     // multiple of BP
   signed char tap_dy[64];
@@ -213,10 +215,14 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
   const int kt = k_ok ? kk / a.C : 0, kc = k_ok ? kk - kt * a.C : 0;
   const int tdy = a.tap_dy[kt], tdx = a.tap_dx[kt];
   const int ohw = a.OH * a.OW;
-  const T* __restrict__ xg = (const T*)a.x;
-  const T* __restrict__ dyg = (const T*)a.dy;
 
-  // pixel coordinates of this thread's NPASS rows, advanced incrementally (no division in the loop)
+  // Staging is branch-free: both operands are read through buffer descriptors, so a row past the pixel range, a column
+  // past N / K or a tap outside the image simply gets an out-of-range offset (hardware returns zeros) instead of a
+  // divergent branch; the pixel coordinates advance by BP per stage with two multiply-shift quotients (no loops).
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
   int pb[NPASS], py[NPASS], px[NPASS];
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
@@ -227,23 +233,30 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
     py[p] = r / a.OW;
     px[p] = r - py[p] * a.OW;
   }
+  const int dy_col = n_ok ? ncol * 2 : -1, x_col = k_ok ? kc * 2 : -1;       // byte offsets of this thread's fixed chunk
+  const int dy_rowb = a.dy_ld * 2, x_pixb = a.x_ld * 2;
   uint4 rdy[NPASS], rx[NPASS];
   auto load_stage = [&](int m0) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int m = m0 + prow + p * RPP;
       const bool ok = m < m_end;
-      uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
-      if (ok && n_ok) vd = *(const uint4*)(dyg + (long)m * a.dy_ld + ncol);
-      if (ok && k_ok) {
-        const int iy = py[p] * a.sy + tdy, ix = px[p] * a.sx + tdx;
-        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
-          vx = *(const uint4*)(xg + (long)((pb[p] * a.IH + iy) * a.IW + ix) * a.x_ld + kc);
-      }
-      rdy[p] = vd; rx[p] = vx;
-      px[p] += BP;                                 // advance to the next stage's pixel
-      while (px[p] >= a.OW) { px[p] -= a.OW; ++py[p]; }
-      while (py[p] >= a.OH) { py[p] -= a.OH; ++pb[p]; }
+      const unsigned od = (ok && dy_col >= 0) ? (unsigned)(m * dy_rowb + dy_col) : OOB;
+      const int iy = py[p] * a.sy + tdy, ix = px[p] * a.sx + tdx;
+      const bool in = ok && x_col >= 0 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      const unsigned ox_ = in ? (unsigned)(((pb[p] * a.IH + iy) * a.IW + ix) * x_pixb + x_col) : OOB;
+      const u4 vd = __builtin_amdgcn_raw_buffer_load_b128(dr, od, 0, 0);
+      const u4 vx = __builtin_amdgcn_raw_buffer_load_b128(xr, ox_, 0, 0);
+      rdy[p] = make_uint4(vd[0], vd[1], vd[2], vd[3]);
+      rx[p] = make_uint4(vx[0], vx[1], vx[2], vx[3]);
+      // advance BP pixels: q rows wrap, then whole images wrap (ranges are tiny: px < OW + BP, py < OH + BP/OW + 1)
+      const int nx = px[p] + BP;
+      const int q = (int)(((unsigned)nx * a.mag_ow) >> 20);
+      px[p] = nx - q * a.OW;
+      const int ny = py[p] + q;
+      const int q2 = (int)(((unsigned)ny * a.mag_oh) >> 20);
+      py[p] = ny - q2 * a.OH;
+      pb[p] += q2;
     }
   };
   auto store_stage = [&](int buf) {
@@ -328,6 +341,8 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   a.pix_per_split = cdiv(cdiv(a.M, splits), 64) * 64;
   splits = cdiv(a.M, a.pix_per_split);
   a.tiles = tiles; a.total = tiles * splits;
+  a.mag_ow = (unsigned)(((1u << 20) + a.OW - 1) / a.OW);
+  a.mag_oh = (unsigned)(((1u << 20) + a.OH - 1) / a.OH);
   dim3 grid(cdiv(a.total, 8) * 8), block(256);
   if (dtype == SY11_F32) {
     if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
@@ -370,6 +385,13 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
   SY11_REQUIRE((long)d->B * d->IH * d->IW < (1L << 31) && (long)d->B * d->OH * d->OW < (1L << 31), "conv2d_wgrad: pixel count overflows int32");
   WgradArgs a{};
   a.x = x; a.dy = dy; a.dw = dw;
+  {
+    const long xb = ((long)d->B * d->IH * d->IW - 1) * d->x_ld * esz + (long)d->C * esz;
+    const long db = ((long)d->B * d->OH * d->OW - 1) * dy_ld * esz + (long)d->N * esz;
+    SY11_REQUIRE(xb < (1L << 31) && db < (1L << 31), "conv2d_wgrad: operand view larger than 2 GiB");
+    SY11_REQUIRE((long)(d->OW + 64) * d->OW < (1L << 20) && (long)(d->OH + 64) * d->OH < (1L << 20), "conv2d_wgrad: output map larger than 960 pixels per side");
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
+  }
   a.T = d->KH * d->KW; a.C = d->C; a.K = a.T * a.C; a.N = d->N;
   a.M = d->B * d->OH * d->OW;
   a.x_ld = d->x_ld; a.dy_ld = dy_ld;
