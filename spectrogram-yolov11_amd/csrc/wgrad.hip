@@ -315,6 +315,16 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
     __syncthreads();
   }
   const int fcol = lane & 31, fh = lane >> 5;
+  if (n0 + TILE <= a.N && k0 + TILE <= a.K) {            // interior tile (the common case): no per-element bounds branches
+    float* base = a.dw + (long)(n0 + wr * (TILE / 2) + 4 * fh) * a.K + k0 + wc * (TILE / 2) + fcol;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FI; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) atomicAdd(base + (long)(i * 32 + (e & 3) + 8 * (e >> 2)) * a.K + j * 32, acc[i][j][e]);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < FI; ++i)
 #pragma unroll
