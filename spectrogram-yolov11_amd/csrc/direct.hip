@@ -534,6 +534,7 @@ struct StemArgs {
   int B, IH, IW, OH, OW, N, y_ld, SH, SW, PH, PW;
   unsigned flags;
   int stat_slots;
+  unsigned mag_ow, mag_oh;     // ceil(2^20 / OW), ceil(2^20 / OH) for the multiply-shift pixel walk (wgrad)
 };
 
 template <typename T, int NMAX>
@@ -744,17 +745,26 @@ __global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a, const BnTa
   for (int gi = wave * 2; gi < wave * 2 + 2; ++gi) {
     const int m = blockIdx.x * 256 + gi * 32 + col;
     const bool ok = m < M;
-    const int mm = ok ? m : M - 1;
-    const int q = mm / a.OW, ox = mm - q * a.OW;
-    const int b = q / a.OH, oy = q - b * a.OH;
+    // the group's first pixel is wave-uniform: decode it on the scalar unit, then walk `col` pixels with multiply-shift wraps
+    const int base = __builtin_amdgcn_readfirstlane(min(blockIdx.x * 256 + gi * 32, M - 1));
+    const int q0 = base / a.OW, b0 = q0 / a.OH;
+    int ox = base - q0 * a.OW + (ok ? col : 0);
+    const int wq = (int)(((unsigned)ox * a.mag_ow) >> 20);
+    ox -= wq * a.OW;
+    int oy = q0 - b0 * a.OH + wq;
+    const int wq2 = (int)(((unsigned)oy * a.mag_oh) >> 20);
+    oy -= wq2 * a.OH;
+    const int b = min(b0 + wq2, a.B - 1);
     const int iy0 = oy * a.SH, ix0 = ox * a.SW;
     const float* xb = a.x + b * plane3 + (long)iy0 * a.IW + ix0;
     ss16x8 af[2];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
+      // unconditional load from a clamped (always legal) address + select: a predicated load per slot compiles to 16
+      // branch-and-wait sequences, i.e. 16 serialised memory latencies per 32 pixels (r01 ISA inspection)
       const bool in = ok && tap[j].ok && (unsigned)(iy0 + tap[j].dy) < (unsigned)a.IH && (unsigned)(ix0 + tap[j].dx) < (unsigned)a.IW;
-      const float v = in ? xb[tap[j].off] : 0.f;
-      af[j >> 3][j & 7] = StemMma<T>::bits(v);
+      const float v = xb[in ? tap[j].off : 0];
+      af[j >> 3][j & 7] = StemMma<T>::bits(in ? v : 0.f);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -838,19 +848,24 @@ __global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* d
     // patch operand: 16 pixels of reduction column `col` for this lane (8*half + 16g + i)
     ss16x8 bf[2];
     {
-      const int pw = min(p0, M - 1);
+      const int pw = __builtin_amdgcn_readfirstlane(min(p0, M - 1));        // wave-uniform: scalar division
       const int q = pw / a.OW;
       int ox = pw - q * a.OW + 8 * half, oy = q % a.OH, b = q / a.OH;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (j == 8) ox += 16;                         // slots 8..15 are pixels 16 + 8*half + (0..7)
-        int oxx = ox + (j & 7), oyy = oy, bb = b;
-        while (oxx >= a.OW) { oxx -= a.OW; if (++oyy >= a.OH) { oyy = 0; ++bb; } }
+        int oxx = ox + (j & 7);
+        const int q = (int)(((unsigned)oxx * a.mag_ow) >> 20);      // row wraps (branch-free: exact for these small ranges)
+        oxx -= q * a.OW;
+        int oyy = oy + q;
+        const int q2 = (int)(((unsigned)oyy * a.mag_oh) >> 20);
+        oyy -= q2 * a.OH;
+        const int bb = b + q2;
         const int pj = p0 + 8 * half + 16 * (j >> 3) + (j & 7);
         const int iy0 = oyy * a.SH, ix0 = oxx * a.SW;
         const bool in = pj < m1 && tap.ok && (unsigned)(iy0 + tap.dy) < (unsigned)a.IH && (unsigned)(ix0 + tap.dx) < (unsigned)a.IW;
-        const float v = in ? a.x[bb * plane3 + (long)iy0 * a.IW + ix0 + tap.off] : 0.f;
-        bf[j >> 3][j & 7] = StemMma<T>::bits(v);
+        const float v = a.x[in ? bb * plane3 + (long)iy0 * a.IW + ix0 + tap.off : 0];      // clamped address + select: no branches
+        bf[j >> 3][j & 7] = StemMma<T>::bits(in ? v : 0.f);
       }
     }
     __syncthreads();
@@ -917,7 +932,9 @@ static int stem_fwd_tail(const sy11_conv_desc* d, const float* x_nchw, const voi
   dim3 grid((unsigned)((M + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype != SY11_F32 && (d->N == 32 || d->N == 64) && d->y_ld == d->N && ((uintptr_t)y & 15) == 0 &&
-      (long)d->B * 3 * d->IH * d->IW < (1L << 31)) {
+      (long)d->B * 3 * d->IH * d->IW < (1L << 31) && (long)(d->OW + 64) * d->OW < (1L << 20) && (long)(d->OH + 64) * d->OH < (1L << 20)) {
+    a.mag_ow = (unsigned)(((1u << 20) + d->OW - 1) / d->OW);
+    a.mag_oh = (unsigned)(((1u << 20) + d->OH - 1) / d->OH);
     SY11_DISPATCH_DTYPE(d->dtype, T, {
       if (d->N == 32) hipLaunchKernelGGL((stem_fwd_mma<T, 1>), grid, block, 0, st, a, tail);
       else hipLaunchKernelGGL((stem_fwd_mma<T, 2>), grid, block, 0, st, a, tail);
@@ -950,6 +967,9 @@ extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw
       (long)d->B * 3 * d->IH * d->IW < (1L << 31)) {
     StemArgs am = a;
     am.y_ld = dy_ld;
+    SY11_REQUIRE((long)(d->OW + 64) * d->OW < (1L << 20) && (long)(d->OH + 64) * d->OH < (1L << 20), "stem_conv_wgrad: output map larger than 960 pixels per side");
+    am.mag_ow = (unsigned)(((1u << 20) + d->OW - 1) / d->OW);
+    am.mag_oh = (unsigned)(((1u << 20) + d->OH - 1) / d->OH);
     long nb = (M + 2047) / 2048;                       // >= 16 chunks of 128 pixels per workgroup, at most 2 workgroups per CU
     if (nb > 512) nb = 512;
     const int ppbm = (int)(((M + nb - 1) / nb + 127) / 128 * 128);
