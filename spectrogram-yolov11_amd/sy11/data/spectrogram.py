@@ -50,7 +50,8 @@ class SpectrogramProducer:
             raise ValueError(f"need >= {self.n_samples} IQ samples per image, got {iq.shape[1]}")
         return ops.stft_logmel(iq, self.window, self.mel_start, self.mel_w, self.n_fft, self.hop, self.n_frames, self.n_mel)
 
-    def __call__(self, iq: torch.Tensor) -> torch.Tensor:
-        """(B, n_samples) complex64 -> (B, 3, n_mel, n_frames) f32 in [0, 1] (NCHW, what the model's stem reads)."""
+    def __call__(self, iq: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """(B, n_samples) complex64 -> (B, 3, n_mel, n_frames) f32 in [0, 1] (NCHW, what the model's stem reads).
+        ``out``: write the image there (the trainer passes the captured graph's static input: no 315 MB copy per step)."""
         db, mm = self.logmel_db(iq)
-        return ops.stft_normalize(db, mm)
+        return ops.stft_normalize(db, mm, out)

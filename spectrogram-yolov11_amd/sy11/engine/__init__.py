@@ -376,7 +376,8 @@ class GraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, entry, n_in, *tensors):
         for dst, src in zip(entry.static_in, tensors[:n_in]):
-            dst.copy_(src)
+            if dst.data_ptr() != src.data_ptr():                    # producers may write straight into the static input
+                dst.copy_(src)
         entry.g_fwd.replay()
         ctx.entry, ctx.n_in, ctx.n_t = entry, n_in, len(tensors)
         ctx.in_req = [t.requires_grad for t in tensors[:n_in]]
@@ -395,6 +396,18 @@ class GraphFn(torch.autograd.Function):
         if hook is not None:
             hook(e.store)
         return (None, None, *gin, *([None] * (ctx.n_t - ctx.n_in)))
+
+
+def graph_static_input(module, shape, dtype=torch.float32):
+    """The static input tensor of a captured graph entry of ``module`` matching (shape, dtype), or None: a producer that
+    writes its output there saves the per-step copy into the graph's input buffer."""
+    cfg = module.__dict__.get("_sy11_graph_cfg")
+    if not cfg:
+        return None
+    for entry in cfg["entries"].values():
+        if len(entry.static_in) == 1 and tuple(entry.static_in[0].shape) == tuple(shape) and entry.static_in[0].dtype == dtype:
+            return entry.static_in[0]
+    return None
 
 
 def enable_graphs(module, warmup: int = 2):

@@ -121,7 +121,10 @@ class DetectionTrainer:
     def preprocess_batch(self, batch):
         """detect/train.py:57-74: uint8 -> float/255; with a producer: raw IQ -> spectrogram image on device."""
         if "iq" in batch and self.producer is not None:
-            batch["img"] = self.producer(batch["iq"].to(self.device, non_blocking=True))
+            from . import graph_static_input
+            iq = batch["iq"].to(self.device, non_blocking=True)
+            shape = (iq.shape[0], 3, self.producer.n_mel, self.producer.n_frames)
+            batch["img"] = self.producer(iq, out=graph_static_input(self.model, shape) if self.model.training else None)
         else:
             img = batch["img"].to(self.device, non_blocking=True)
             batch["img"] = img.float() / 255 if img.dtype == torch.uint8 else img.float()

@@ -305,9 +305,12 @@ def stft_logmel(iq, window, mel_start, mel_w, n_fft, hop, n_frames, n_mel):
     return db, mm
 
 
-def stft_normalize(db, mm):
+def stft_normalize(db, mm, out=None):
     B, n_frames, n_mel = db.shape
-    img = torch.empty((B, 3, n_mel, n_frames), dtype=torch.float32, device=db.device)
+    if out is not None and (tuple(out.shape) != (B, 3, n_mel, n_frames) or out.dtype != torch.float32 or not out.is_contiguous()
+                            or out.device != db.device):
+        raise _lib.Sy11Error("stft_normalize: `out` must be a contiguous f32 (B, 3, n_mel, n_frames) tensor on the same device")
+    img = out if out is not None else torch.empty((B, 3, n_mel, n_frames), dtype=torch.float32, device=db.device)
     call("sy11_stft_normalize", B, n_mel, n_frames, _p(db), _p(mm), _p(img), _stream())
     return img
 
