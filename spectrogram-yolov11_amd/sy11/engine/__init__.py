@@ -388,7 +388,7 @@ class GraphFn(torch.autograd.Function):
         e = ctx.entry
         e.store.begin_backward(e.static_in[0].device)               # zeroes the flat buffer at the start of a window
         for dst, g in zip(e.static_gout, gouts):
-            if g is not None and dst.dim() == 4:
+            if g is not None and dst.dim() == 4 and g.data_ptr() != dst.data_ptr():      # the criterion may have written in place
                 dst.copy_(g.permute(0, 2, 3, 1))
         e.g_bwd.replay()
         gin = [(g.float() if (req and g is not None) else None) for g, req in zip(e.static_gin, ctx.in_req)]
@@ -408,6 +408,14 @@ def graph_static_input(module, shape, dtype=torch.float32):
         if len(entry.static_in) == 1 and tuple(entry.static_in[0].shape) == tuple(shape) and entry.static_in[0].dtype == dtype:
             return entry.static_in[0]
     return None
+
+
+def graph_static_gout(module):
+    """Static output-gradient tensors (NHWC) of the module's captured backward graph, or None (single captured signature only)."""
+    cfg = module.__dict__.get("_sy11_graph_cfg")
+    if not cfg or len(cfg["entries"]) != 1:
+        return None
+    return next(iter(cfg["entries"].values())).static_gout
 
 
 def enable_graphs(module, warmup: int = 2):

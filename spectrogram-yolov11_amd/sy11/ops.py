@@ -358,8 +358,13 @@ def det_loss_forward(maps, strides, nc, gt):
     return w
 
 
-def det_loss_backward(w: DetLossWorkspace, upstream_over_tss: torch.Tensor, gains):
-    dmaps = [torch.empty_like(m) for m in w.maps]
+def det_loss_backward(w: DetLossWorkspace, upstream_over_tss: torch.Tensor, gains, out=None):
+    """d loss / d maps.  ``out``: optional list of NHWC f32 buffers to write into (the captured backward graph's static
+    output-gradient tensors) — used when every shape matches, else fresh tensors are returned."""
+    if out is not None and len(out) == w.nl and all(o.shape == m.shape and o.dtype == m.dtype and o.is_contiguous() for o, m in zip(out, w.maps)):
+        dmaps = list(out)
+    else:
+        dmaps = [torch.empty_like(m) for m in w.maps]
     dptrs = (C.c_void_p * w.nl)(*[d.data_ptr() for d in dmaps])
     cast = lambda a: C.cast(a, C.c_void_p)
     call("sy11_det_loss_bwd", w.B, w.nc, w.nl, cast(w.ptrs), cast(dptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt),

@@ -71,7 +71,7 @@ class _FusedLossFn(torch.autograd.Function):
         from .. import ops as K
         crit = ctx.crit
         up = (gloss.float() / ctx.tss).reshape(1).contiguous()
-        dmaps = K.det_loss_backward(ctx.w, up, (crit.hyp.box, crit.hyp.cls, crit.hyp.dfl))
+        dmaps = K.det_loss_backward(ctx.w, up, (crit.hyp.box, crit.hyp.cls, crit.hyp.dfl), out=crit.__dict__.get("grad_out"))
         return (None, None, *[d.permute(0, 3, 1, 2) for d in dmaps])
 
 
