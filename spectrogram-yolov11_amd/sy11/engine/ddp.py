@@ -44,7 +44,13 @@ def attach(model: torch.nn.Module, group=None):
     if store is None:
         store = GradStore(model)
         model.__dict__["_sy11_grads"] = store
-    module_post_backward[id(store)] = lambda s: allreduce_flat(s.flat, group)
+    # gradient accumulation (accumulate > 1): the flat buffer sums the micro-steps, so it must be all-reduced ONCE, after the
+    # last backward of the window (the trainer raises ``store.defer_allreduce`` on the others) — reducing it after every
+    # backward would re-sum the already reduced part.  SUM is linear: allreduce(sum_k g_k) == sum_k allreduce(g_k).
+    def hook(s):
+        if not getattr(s, "defer_allreduce", False):
+            allreduce_flat(s.flat, group)
+    module_post_backward[id(store)] = hook
     return model
 
 

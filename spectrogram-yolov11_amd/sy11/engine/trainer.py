@@ -155,8 +155,12 @@ class DetectionTrainer:
         self.model.train()
         batch = self.preprocess_batch(batch)
         loss, items = self.model(batch)
+        will_step = self.ni - self.last_opt_step >= self.accumulate
+        store = self.model.__dict__.get("_sy11_grads")
+        if store is not None:
+            store.defer_allreduce = not will_step                # data parallel: one gradient all-reduce per optimizer step
         self.scaler.scale(loss).backward()
-        if self.ni - self.last_opt_step >= self.accumulate:      # trainer.py:391 (ni counts from 0, last_opt_step from -1)
+        if will_step:                                            # trainer.py:391 (ni counts from 0, last_opt_step from -1)
             self.optimizer_step()
             self.last_opt_step = self.ni
         self.ni += 1

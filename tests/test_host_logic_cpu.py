@@ -240,3 +240,28 @@ def test_flat_state_alignment_and_views():
     assert gs.grad_vec(m.f.gsc2.alpha).reshape(-1).data_ptr() == gs.views[id(m.f.gsc2.alpha)].data_ptr()   # a view, not a copy
     for (s0, s1), g in zip(fs.group_slices, fs.group_tensors(gs.flat)):
         assert g.numel() == s1 - s0
+
+
+def test_allreduce_hook_defers_inside_an_accumulation_window():
+    """ddp.attach's hook reduces the flat gradient buffer only when the trainer says the window is complete."""
+    from sy11.engine import GradStore, module_post_backward
+    from sy11.engine import ddp
+    from sy11.nn.modules import Conv
+    m = Conv(8, 16, 3)
+    calls = []
+    orig = ddp.allreduce_flat
+    ddp.allreduce_flat = lambda flat, group=None: calls.append(flat.data_ptr())
+    try:
+        ddp.attach(m)
+        store = m.__dict__["_sy11_grads"]
+        store.begin_backward(torch.device("cpu"))
+        hook = module_post_backward[id(store)]
+        store.defer_allreduce = True
+        hook(store)
+        assert calls == []
+        store.defer_allreduce = False
+        hook(store)
+        assert calls == [store.flat.data_ptr()]
+    finally:
+        ddp.allreduce_flat = orig
+        module_post_backward.pop(id(m.__dict__["_sy11_grads"]), None)
