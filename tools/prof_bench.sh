@@ -1,8 +1,17 @@
-# rocprofv3 kernel trace + stats of the default bench (graph replay), summaries copied by the caller into profiles/
+# rocprofv3 profiles of the default bench command; the caller copies the summaries into profiles/.
+#   bash tools/prof_bench.sh stats <tag>   kernel trace + per-kernel statistics (graph replay, the bench as the driver runs it)
+#   bash tools/prof_bench.sh pmc <tag>     HBM traffic counters, one pass per counter (eager launches: counters are per dispatch)
 set -e
+MODE=$1; TAG=$2
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d $OUT -o run -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench.json 2> $OUT/bench.err
-ls $OUT $OUT/* | head -30
+if [ "$MODE" = stats ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench.json 2> $OUT/bench.err
+else
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o run -- python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-graphs > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+  done
+fi
+find $OUT -type f | head -30
