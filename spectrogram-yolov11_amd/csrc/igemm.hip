@@ -467,10 +467,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // ------------------------------------------------------------------------------------------------ host side
 // cfg: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x128 (pixels x channels per workgroup), all with 64-byte K stages;
 // 4..6 = the first three with 128-byte K stages (half the barriers per K, 2 workgroups per CU instead of 4)
-constexpr int IGEMM_NCFG = 7;
+// 7, 8 = persistent 1x1 kernel (igemm1x1.hip) with 128 / 64 channels per workgroup
+constexpr int IGEMM_NCFG = 9;
+int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq, int M, int N, int K, int x_ld,
+                          int y_ld, int stat_slots, int stat_stride, unsigned x_bytes, unsigned w_bytes, int epi, int nostore, int bn,
+                          hipStream_t st);
+static int epi_code(const IgemmArgs& a) {
+  return (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
+         ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
+}
 template <typename T>
 static bool cfg_legal(const IgemmArgs& a, int cfg) {
   if (cfg < 0 || cfg >= IGEMM_NCFG) return false;
+  if (cfg >= 7) {
+    const int epi = epi_code(a), bn = cfg == 7 ? 128 : 64;
+    if (std::is_same<T, float>::value || a.T != 1 || a.tap_dy[0] || a.tap_dx[0] || a.sy != 1 || a.sx != 1 || !a.dense_out || !a.vec_out) return false;
+    if ((epi != 0 && epi != 1 && epi != 8) || a.K % 32 || a.K != a.C || a.wK != a.K || a.N % 8 || a.debug) return false;
+    if (cfg == 7 && a.N <= 64) return false;                 // 128 channels per workgroup only when there are that many
+    if (cfg == 8 && a.N <= 32) return false;
+    return (size_t)(a.K / 32) * 64 * (bn + 256) + (size_t)128 * bn * 2 <= 150 * 1024;
+  }
   if (cfg >= 4) return a.K >= 256;                     // long stages only pay with enough K to amortise them
   if (cfg != 3) return true;
   const int epi = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
@@ -480,6 +496,9 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
 
 template <typename T>
 static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
+  if (cfg >= 7)
+    return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
+                                 a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st);
   const int bm = cfg == 3 ? 256 : 128;
   const int tile = cfg >= 4 ? cfg - 4 : cfg;
   const int bn = tile == 1 ? 64 : (tile == 2 ? 32 : 128);
@@ -547,7 +566,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
     } else if (!sy11tune::capturing(st)) {
       int cands[IGEMM_NCFG], nc = 0;
       for (int c = 0; c < IGEMM_NCFG; ++c) {
-        const int ct = c >= 4 ? c - 4 : c;
+        const int ct = c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c);
         const int cbn = ct == 1 ? 64 : (ct == 2 ? 32 : 128);
         if (cbn > 32 && cbn >= 2 * a.N) continue;                        // tile more than twice the channel count: pure waste
         if (cfg_legal<T>(a, c)) cands[nc++] = c;
