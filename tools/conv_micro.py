@@ -20,10 +20,12 @@ def main():
     dx = torch.empty_like(x)
     dw = torch.zeros(N, k, k, C, device="cuda")
     wt = ops.weight_transpose(w)
-    st = torch.zeros(2, 32, N, device="cuda")
+    st = torch.zeros(2, 128 if B * OH * OW >= 819200 else 32, N, device="cuda")
     def run():
         if mode == "fwd":
             ops.conv2d_fwd(x, w, y, k, s, p, stats=(st[0], st[1]))
+        elif mode == "fwd_nostats":
+            ops.conv2d_fwd(x, w, y, k, s, p)
         elif mode == "dgrad":
             ops.conv2d_dgrad(dy, wt, dx, (B, OH, OW, N), k, s, p)
         else:
