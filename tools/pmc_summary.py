@@ -30,7 +30,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
 def family(k):
     if "wgrad16_kernel" in k or re.search(r"\bwgrad_kernel", k):
         return "sy11_conv2d_wgrad"
-    if "igemm_kernel" in k:
+    if "igemm" in k:
         return "sy11_conv2d_fwd+dgrad"
     for f in ("bn_bwd_reduce", "bn_bwd_apply", "bn_act_fwd", "stem_fwd", "stem_wgrad", "dw3x3", "dwconv_wgrad", "stft_logmel", "attention"):
         if f in k:
