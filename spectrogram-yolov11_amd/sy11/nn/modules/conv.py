@@ -133,6 +133,18 @@ class Conv(nn.Module):
         if w is None:
             w = working_filter(conv, conv.weight, ec.dtype, ec.capturing)
         stem = x.raw is not None and C1 == 3 and k == 3 and g == 1 and d == 1 and N <= 64
+        # input channel count that is not a whole number of 16-byte vectors (the 3-channel image in front of a stem wider than
+        # 64, e.g. yolo11x: 96): run the dense kernels on zero-padded channels — zeros contribute nothing to y, dw gets sliced
+        epc = 16 // torch.empty((), dtype=ec.dtype).element_size()
+        padded = (not stem) and g == 1 and C1 % epc != 0
+        x_real, w_real = x, w
+        if padded:
+            Cp = -(-C1 // epc) * epc
+            xp = torch.zeros((B, H, W, Cp), dtype=ec.dtype, device=ec.device)
+            xp[..., :C1].copy_(x.data)
+            wp = torch.zeros((N, k, k, Cp), dtype=w.dtype, device=w.device)
+            wp[..., :C1].copy_(w)
+            x, w = Act(xp, req=False), wp
         if out is None:
             out = Act(ec.empty(B, OH, OW, N))
         bn = getattr(self, "bn", None)
@@ -202,9 +214,21 @@ class Conv(nn.Module):
                     dw = gs.grad_krsc(conv.weight)
                     if stem:
                         ec.on_side(lambda: ops.stem_conv_wgrad(x.raw, dy, dw, s, p), x.raw, dy)
+                    elif padded:
+                        dwp = torch.zeros(tuple(w.shape), dtype=torch.float32, device=ec.device)
+                        ops.conv2d_wgrad(x.data, dy, dwp, k, s, p, d, g)
+                        dw.add_(dwp[..., :C1])
                     else:
                         xd = x.data
                         ec.on_side(lambda: ops.conv2d_wgrad(xd, dy, dw, k, s, p, d, g), xd, dy)
+                if padded and x_real.req:
+                    gp = torch.zeros_like(x.data)
+                    ops.conv2d_dgrad(dy, ops.weight_transpose(w), gp, (B, OH, OW, N), k, s, p, d, 1, accumulate=True)
+                    gx, acc = x_real.grad_for_write()
+                    if acc:
+                        gx.add_(gp[..., :C1])
+                    else:
+                        gx.copy_(gp[..., :C1])
                 if x.req:
                     gx, acc = x.grad_for_write()
                     if g == 1 or g != C1 or g != N:          # dense, or grouped as `g` dense slices (DDWConv g = 8)

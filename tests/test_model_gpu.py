@@ -216,3 +216,29 @@ def test_model_vs_oracle_fresh_inputs_yolo11n(dtype, tol):
             bad.append((k, d, osd[k].grad.norm().item()))
     assert not bad, bad[:8]
     assert float(np.median(rels)) <= (2e-3 if dtype == torch.float32 else 8e-2), float(np.median(rels))
+
+
+@pytest.mark.parametrize("scale,n_params", [("n", 2624080), ("s", 9458752), ("m", 20114688), ("l", 25372160), ("x", 56966176)])
+def test_every_yaml_scale_trains_and_matches_oracle_loss(scale, n_params):
+    """All five scales of cfg/models/11/yolo11.yaml (parameter counts of the yaml header comments): one fp32 train step at
+    2x3x64x64 vs the oracle.  Scale x has a 96-channel stem: the 3-channel image goes through the dense kernels on
+    zero-padded channels instead of the dedicated stem kernels (N <= 64)."""
+    from sy11.nn.tasks import DetectionModel
+    m = DetectionModel(f"yolo11{scale}.yaml", nc=80, verbose=False)
+    assert sum(p.numel() for p in m.parameters()) == n_params
+    m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    layers = R.resolve_graph(scale, nc=80)
+    sd = R.seeded_state_dict(R.empty_state_dict(layers), seed=2)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    img = R.seeded_image((2, 3, 64, 64), seed=11)
+    batch = {"img": img.to(DEV), "batch_idx": torch.tensor([0., 1.]).to(DEV), "cls": torch.tensor([[7.], [33.]]).to(DEV),
+             "bboxes": torch.tensor([[0.5, 0.5, 0.5, 0.4], [0.4, 0.6, 0.3, 0.5]]).to(DEV)}
+    loss, items = m(batch)
+    loss.backward()
+    osd = {k: v.clone() for k, v in sd.items()}
+    maps = R.forward(osd, layers, img, train=True)
+    oloss, _ = loss_ref.detection_loss(maps, {k: v.cpu() for k, v in batch.items()}, nc=80)
+    assert abs(loss.item() - oloss.item()) <= 2e-3 * abs(oloss.item()), (scale, loss.item(), oloss.item())
+    g0 = dict(m.named_parameters())["model.0.conv.weight"].grad
+    assert g0 is not None and torch.isfinite(g0).all() and float(g0.abs().max()) > 0
