@@ -792,25 +792,28 @@ static bool att_mma_ok(int dtype, int N, int kd, int hd, const void* a, int a_ld
          (((uintptr_t)a | (uintptr_t)b2) & 15) == 0;
 }
 
-static int att_check(int dtype, int B, int N, int heads, int kd, int hd, const char* who) {
+static int att_check(int dtype, int B, int N, int heads, int kd, int hd, const char* who, bool mma) {
   SY11_REQUIRE(dtype_ok(dtype) && B > 0 && N > 0 && heads > 0 && kd > 0 && hd > 0, "%s: bad dims", who);
   SY11_REQUIRE(kd <= 64 && hd <= 128 && 32 * (kd + hd) <= 16 * 256, "%s: kd<=64, hd<=128 supported", who);
   SY11_REQUIRE(heads <= 65535 && B <= 65535, "%s: heads/B exceed grid limits", who);
-  const size_t lds = (size_t)(ATT_QT * N + ATT_QT * (kd > hd ? kd : hd) + 64 * ((kd > hd ? kd : hd) + 1)) * 4;
-  SY11_REQUIRE(lds <= 160 * 1024, "%s: N=%d needs %zu bytes of LDS (>160 KiB)", who, N, lds);
+  if (!mma) {                                    // the VALU kernels keep 32 score rows of N floats in LDS; the MFMA path does not
+    const size_t lds = (size_t)(ATT_QT * N + ATT_QT * (kd > hd ? kd : hd) + 64 * ((kd > hd ? kd : hd) + 1)) * 4;
+    SY11_REQUIRE(lds <= 160 * 1024, "%s: N=%d needs %zu bytes of LDS (>160 KiB)", who, N, lds);
+  }
   return SY11_OK;
 }
 
 extern "C" int sy11_attention_fwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
                                   int32_t qkv_ld, void* o, int32_t o_ld, float* p, void* stream) {
-  int rc = att_check(dtype, B, N, heads, kd, hd, "attention_fwd");
+  const bool use_mma = att_mma_ok(dtype, N, kd, hd, qkv, qkv_ld, o, o_ld) && ((uintptr_t)p & 15) == 0;
+  int rc = att_check(dtype, B, N, heads, kd, hd, "attention_fwd", use_mma);
   if (rc) return rc;
   SY11_REQUIRE(qkv && o && p && qkv_ld >= heads * (2 * kd + hd) && o_ld >= heads * hd, "attention_fwd: bad pointer/stride");
   const size_t lds = (size_t)(ATT_QT * N + ATT_QT * kd + 64 * (kd + 1)) * 4;
   dim3 grid(cdiv(N, ATT_QT), heads, B), block(256);
   const float scale = 1.0f / sqrtf((float)kd);
   hipStream_t st = (hipStream_t)stream;
-  if (att_mma_ok(dtype, N, kd, hd, qkv, qkv_ld, o, o_ld) && ((uintptr_t)p & 15) == 0) {
+  if (use_mma) {
     dim3 gm(cdiv(cdiv(N, 32), 4), heads, B);
     SY11_DISPATCH_DTYPE(dtype, T, {
       hipLaunchKernelGGL((attention_fwd_mma<T>), gm, block, 0, st, B, N, heads, (const T*)qkv, qkv_ld, (T*)o, o_ld, p, scale);
@@ -838,7 +841,9 @@ extern "C" int sy11_attention_fwd(int32_t dtype, int32_t B, int32_t N, int32_t h
 extern "C" int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
                                   int32_t qkv_ld, const float* p, const void* d_o, int32_t do_ld, void* dqkv, int32_t dqkv_ld,
                                   float* workspace, void* stream) {
-  int rc = att_check(dtype, B, N, heads, kd, hd, "attention_bwd");
+  const bool use_mma = att_mma_ok(dtype, N, kd, hd, qkv, qkv_ld, d_o, do_ld) && dqkv_ld % 8 == 0 && (((uintptr_t)dqkv | (uintptr_t)p) & 15) == 0 &&
+                       (size_t)cdiv(N, 32) * 32 * 64 <= 150 * 1024;
+  int rc = att_check(dtype, B, N, heads, kd, hd, "attention_bwd", use_mma);
   if (rc) return rc;
   SY11_REQUIRE(qkv && p && d_o && dqkv && workspace, "attention_bwd: null pointer");
   SY11_REQUIRE(qkv_ld >= heads * (2 * kd + hd) && dqkv_ld >= heads * (2 * kd + hd) && do_ld >= heads * hd, "attention_bwd: bad stride");
@@ -846,12 +851,13 @@ extern "C" int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t h
   const float scale = 1.0f / sqrtf((float)kd);
   hipStream_t st = (hipStream_t)stream;
   dim3 gq(cdiv(N, ATT_QT), heads, B), gk(cdiv(N, 32), heads, B), block(256);
-  if (att_mma_ok(dtype, N, kd, hd, qkv, qkv_ld, d_o, do_ld) && dqkv_ld % 8 == 0 && (((uintptr_t)dqkv | (uintptr_t)p) & 15) == 0) {
+  if (use_mma) {
     const int ntile = cdiv(N, 32);
     dim3 gm(cdiv(ntile, 4), heads, B);
     const size_t lq = (size_t)ntile * 32 * 64, lk = (size_t)2 * (32 * 192 + 32 * 64) + (size_t)ntile * 32 * 4;
-    SY11_REQUIRE(lq <= 64 * 1024 && lk <= 64 * 1024, "attention_bwd: N=%d too large for the MFMA path", N);
     SY11_DISPATCH_DTYPE(dtype, T, {
+      if (lq > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_bwd_q_mma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+      if (lk > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_bwd_kv_mma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lk);
       hipLaunchKernelGGL((attention_bwd_q_mma<T>), gm, block, lq, st, B, N, heads, (const T*)qkv, qkv_ld, p, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, workspace, scale);
       hipLaunchKernelGGL((attention_bwd_kv_mma<T>), gm, block, lk, st, B, N, heads, (const T*)qkv, qkv_ld, p, (const float*)workspace, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, scale);
     });

@@ -243,9 +243,11 @@ def test_copy_upsample_maxpool(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("B,H,W,heads", [(2, 6, 5, 2), (1, 20, 20, 4), (2, 3, 3, 1), (3, 10, 10, 2), (2, 8, 4, 1)])
+@pytest.mark.parametrize("B,H,W,heads", [(2, 6, 5, 2), (1, 20, 20, 4), (2, 3, 3, 1), (3, 10, 10, 2), (2, 8, 4, 1), (1, 40, 40, 2)])
 def test_attention_fwd_bwd(B, H, W, heads, dtype):
     o = ops()
+    if H * W > 1200 and dtype == torch.float32:
+        pytest.skip("f32 attention keeps 32 score rows of N floats in LDS: N <= ~1200 tokens (the MFMA f16/bf16 path has no such limit)")
     kd, hd = 32, 64
     N = H * W
     Cq = heads * (2 * kd + hd)
