@@ -37,6 +37,11 @@ class DetectionTrainer:
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp)
         self.accumulate = max(round(self.args.nbs / (batch_size * world_size)), 1)
         wd = self.args.weight_decay * batch_size * world_size * self.accumulate / self.args.nbs
+        if self.args.optimizer == "auto":                   # trainer.py:778-786: the default of the reference's cfg
+            nc = getattr(self.model, "nc", None) or self.model.model[-1].nc
+            iterations = getattr(self.args, "iterations", 100000)
+            name, lr, mom = ("SGD", 0.01, 0.9) if iterations > 10000 else ("AdamW", round(0.002 * 5 / (4 + nc), 6), 0.9)
+            self.args.optimizer, self.args.lr0, self.args.momentum, self.args.warmup_bias_lr = name, lr, mom, 0.0
         self.flat = None
         if flat:
             # parameters / buffers re-homed into flat buffers; 3 optimizer groups = 3 slices (see engine/flat.py)

@@ -70,15 +70,20 @@ def test_accumulation_window_and_grad_views():
     assert gs.flat.abs().sum() == 0                                # gradients cleared after the optimizer step
 
 
-def test_flat_state_matches_per_tensor_optimizer():
-    """Flat-slice SGD/EMA (3 tensors) and the reference-style per-tensor optimizer/ModelEMA give the same weights."""
+@pytest.mark.parametrize("opt", [{}, {"optimizer": "auto", "iterations": 500}])
+def test_flat_state_matches_per_tensor_optimizer(opt):
+    """Flat-slice optimizer/EMA (3 tensors, fused kernels) and the reference-style per-tensor optimizer/ModelEMA give the same
+    weights — for SGD-nesterov and for the AdamW that `optimizer=auto` picks on short runs (trainer.py:778-786)."""
     from sy11.engine.trainer import DetectionTrainer
     from sy11.nn.tasks import DetectionModel
 
     def mk(flat):
         m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
         m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
-        return DetectionTrainer(m, batch_size=4, device=DEV, overrides={"amp": False, "nbs": 4}, graphs=False, flat=flat)
+        t = DetectionTrainer(m, batch_size=4, device=DEV, overrides={"amp": False, "nbs": 4, **opt}, graphs=False, flat=flat)
+        if opt:
+            assert type(t.optimizer).__name__ == "AdamW" and abs(t.args.lr0 - round(0.002 * 5 / 84, 6)) < 1e-12
+        return t
     ta, tb = mk(True), mk(False)
     for i in range(3):
         b = batch(10 + i)
@@ -86,10 +91,13 @@ def test_flat_state_matches_per_tensor_optimizer():
         tb.train_step(dict(b))
     sa, sb = ta.model.state_dict(), tb.model.state_dict()
     assert list(sa) == list(sb)
+    # AdamW moves every element by ~lr per step whatever the gradient's size: elements whose exact gradient is ~0 (filters in
+    # front of a BatchNorm are scale-invariant) get a sign decided by summation-order noise -> bound = steps * lr, not 2e-4
+    atol = 2e-4 if not opt else 3 * ta.args.lr0 * 1.5
     for k in sa:
         if sa[k].dtype.is_floating_point:
-            assert torch.allclose(sa[k], sb[k], rtol=2e-3, atol=2e-4), k
+            assert torch.allclose(sa[k], sb[k], rtol=2e-3, atol=atol), k
     ea, eb = ta.ema.ema.state_dict(), tb.ema.ema.state_dict()
     for k in ea:
         if ea[k].dtype.is_floating_point:
-            assert torch.allclose(ea[k], eb[k], rtol=2e-3, atol=2e-4), k
+            assert torch.allclose(ea[k], eb[k], rtol=2e-3, atol=atol), k
