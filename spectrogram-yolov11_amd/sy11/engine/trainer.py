@@ -123,6 +123,42 @@ class DetectionTrainer:
                 opt.state[t]["momentum_buffer"] = torch.zeros_like(t)
         return opt
 
+    # ---- learning-rate schedule and warm-up (engine/trainer.py:209-215, :330, :364-377, :430-433)
+    def set_schedule(self, batches_per_epoch, epochs, lrf=0.01, cos_lr=False):
+        """Arm the per-iteration warm-up and the per-epoch LambdaLR of the reference for a run of ``epochs`` x ``batches_per_epoch``."""
+        import math
+        self.nb, self.epochs, self.epoch = int(batches_per_epoch), int(epochs), 0
+        if cos_lr:
+            self.lf = lambda x: max((1 - math.cos(x * math.pi / self.epochs)) / 2, 0) * (lrf - 1) + 1      # one_cycle(1, lrf, epochs)
+        else:
+            self.lf = lambda x: max(1 - x / self.epochs, 0) * (1.0 - lrf) + lrf
+        for g in self.optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+            g["lr"] = g["initial_lr"] * self.lf(0)
+        self.nw = max(round(self.args.warmup_epochs * self.nb), 100) if self.args.warmup_epochs > 0 else -1
+        self.last_opt_step = -1
+        self.ni = 0
+
+    def _warmup(self):
+        """Per-iteration warm-up: bias lr falls from warmup_bias_lr, the other lrs rise from 0, momentum rises from
+        warmup_momentum, the accumulation window grows from 1 to nbs / batch_size."""
+        ni = self.ni
+        if getattr(self, "nw", -1) < 0 or ni > self.nw:
+            return
+        import numpy as np
+        xi = [0, self.nw]
+        self.accumulate = max(1, int(np.interp(ni, xi, [1, self.args.nbs / (self.batch_size * self.world_size)]).round()))
+        for j, g in enumerate(self.optimizer.param_groups):
+            g["lr"] = float(np.interp(ni, xi, [self.args.warmup_bias_lr if j == 0 else 0.0, g["initial_lr"] * self.lf(self.epoch)]))
+            if "momentum" in g:
+                g["momentum"] = float(np.interp(ni, xi, [self.args.warmup_momentum, self.args.momentum]))
+
+    def end_epoch(self):
+        """scheduler.step() of the reference: lr = initial_lr * lf(epoch) for the next epoch."""
+        self.epoch += 1
+        for g in self.optimizer.param_groups:
+            g["lr"] = g["initial_lr"] * self.lf(self.epoch)
+
     def preprocess_batch(self, batch):
         """detect/train.py:57-74: uint8 -> float/255; with a producer: raw IQ -> spectrogram image on device."""
         if "iq" in batch and self.producer is not None:
@@ -158,6 +194,7 @@ class DetectionTrainer:
         """One iteration of the hot loop (trainer.py:378-393): preprocess, forward+loss, scaled backward
         (+ RCCL gradient sum), optimizer step every ``accumulate`` iterations."""
         self.model.train()
+        self._warmup()
         batch = self.preprocess_batch(batch)
         loss, items = self.model(batch)
         will_step = self.ni - self.last_opt_step >= self.accumulate

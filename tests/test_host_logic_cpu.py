@@ -265,3 +265,39 @@ def test_allreduce_hook_defers_inside_an_accumulation_window():
     finally:
         ddp.allreduce_flat = orig
         module_post_backward.pop(id(m.__dict__["_sy11_grads"]), None)
+
+
+def test_trainer_warmup_and_lr_schedule_follow_the_reference_rules():
+    """engine/trainer.py:330 (nw), :364-377 (per-iteration warm-up), :209-215 + LambdaLR (per-epoch decay), on the host only."""
+    import numpy as np
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+    m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
+    t = DetectionTrainer(m, batch_size=16, device="cpu", overrides={"amp": False}, graphs=False)
+    assert t.accumulate == 4                                       # nbs 64 / batch 16
+    t.set_schedule(batches_per_epoch=50, epochs=10, lrf=0.01)
+    assert t.nw == 150                                             # max(round(3.0 * 50), 100)
+    names = [type(t.optimizer).__name__] + [len(g["params"]) for g in t.optimizer.param_groups]
+    assert names[0] == "SGD" and len(t.optimizer.param_groups) == 3
+    t.ni = 0
+    t._warmup()
+    lrs = [g["lr"] for g in t.optimizer.param_groups]
+    assert abs(lrs[0] - 0.1) < 1e-12 and lrs[1] == 0.0 and lrs[2] == 0.0          # group 0 = biases
+    assert all(abs(g["momentum"] - 0.8) < 1e-12 for g in t.optimizer.param_groups) and t.accumulate == 1
+    t.ni = 75
+    t._warmup()
+    exp_other = float(np.interp(75, [0, 150], [0.0, 0.01 * 1.0]))
+    assert abs(t.optimizer.param_groups[1]["lr"] - exp_other) < 1e-12
+    assert abs(t.optimizer.param_groups[0]["lr"] - float(np.interp(75, [0, 150], [0.1, 0.01]))) < 1e-12
+    assert abs(t.optimizer.param_groups[2]["momentum"] - float(np.interp(75, [0, 150], [0.8, 0.937]))) < 1e-12
+    assert t.accumulate == max(1, int(np.interp(75, [0, 150], [1, 4]).round()))
+    t.ni = 151
+    t.accumulate = 4
+    t._warmup()                                                    # past warm-up: nothing changes
+    assert t.accumulate == 4
+    for _ in range(5):
+        t.end_epoch()
+    assert abs(t.optimizer.param_groups[1]["lr"] - 0.01 * ((1 - 5 / 10) * 0.99 + 0.01)) < 1e-12
+    t2 = DetectionTrainer(DetectionModel("yolo11n.yaml", nc=80, verbose=False), batch_size=16, device="cpu",
+                          overrides={"amp": False, "optimizer": "auto", "iterations": 300}, graphs=False)
+    assert type(t2.optimizer).__name__ == "AdamW" and abs(t2.args.lr0 - round(0.002 * 5 / 84, 6)) < 1e-15 and t2.args.warmup_bias_lr == 0.0
