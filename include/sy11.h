@@ -27,7 +27,7 @@ extern "C" {
 #define SY11_VERSION 100
 
 enum sy11_status { SY11_OK = 0, SY11_EINVAL = -1, SY11_EUNSUPPORTED = -2, SY11_ELAUNCH = -3 };
-enum sy11_dtype { SY11_F32 = 0, SY11_F16 = 1, SY11_BF16 = 2 };
+enum sy11_dtype { SY11_F32 = 0, SY11_F16 = 1, SY11_BF16 = 2, SY11_U8 = 3 /* image entries only */ };
 
 /* epilogue / behaviour flags for the conv entry points */
 #define SY11_EPI_SILU 1u       /* y = silu(acc + bias)                                   */
@@ -238,6 +238,25 @@ int sy11_stft_minmax_init(int32_t B, float* minmax, void* stream);
 /* img[b,c,f,t] = (db[b,t,f]-min)/(max-min), c = 0..2, NCHW f32 (what preprocess_batch hands the model)        */
 int sy11_stft_normalize(int32_t B, int32_t n_mel, int32_t n_frames, const float* db, const float* minmax,
                         float* img_nchw, void* stream);
+
+/* ---- image side of preprocess --------------------------------------------------------------
+ * batch["img"].float() / 255 of DetectionTrainer.preprocess_batch (models/yolo/detect/train.py:59): n uint8 values
+ * -> dtype (true division by 255.0f then rounding to dtype)                                                        */
+int sy11_image_u8_to_float(int32_t dtype, int64_t n, const uint8_t* x, void* y, void* stream);
+/* the multi_scale branch of preprocess_batch (models/yolo/detect/train.py:60-73): F.interpolate(imgs size=ns
+ * mode="bilinear" align_corners=False) on `planes` = B*C planes of IH x IW -> OH x OW.  x_dtype may be SY11_U8:
+ * the taps are then divided by 255 first (uint8 batch resized in the same pass)                                    */
+int sy11_image_resize_bilinear(int32_t x_dtype, int32_t y_dtype, int32_t planes, int32_t IH, int32_t IW, int32_t OH,
+                               int32_t OW, const void* x, void* y, void* stream);
+/* LetterBox.__call__ (data/augment.py:1544-1591) fused with BasePredictor.preprocess (engine/predictor.py:118-136):
+ * src (sh x sw x 3) uint8 HWC -> cv2.resize(INTER_LINEAR) to new_h x new_w placed at (top left) on an H x W canvas
+ * filled with `fill` (114); reverse_c swaps channel 0 and 2 (BGR->RGB); chw=1 writes (3 H W) planes else (H W 3);
+ * dtype SY11_U8 keeps bytes (the dataset stage) otherwise value / 255 in dtype (the predictor stage).
+ * The 8-bit bilinear follows OpenCV imgproc/src/resize.cpp (opencv-python is a reference dependency and is not
+ * vendored): 11-bit coefficients; the ((b*(S>>4))>>16 + ... + 2)>>2 vertical pass; exact 2x shrink = 2x2 box mean */
+int sy11_image_letterbox(int32_t dtype, int32_t sh, int32_t sw, int32_t H, int32_t W, int32_t new_h, int32_t new_w,
+                         int32_t top, int32_t left, int32_t fill, int32_t reverse_c, int32_t chw,
+                         const uint8_t* src, void* dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("SY11_LIB", _HERE / "libsy11.so"))
 
-F32, F16, BF16 = 0, 1, 2
+F32, F16, BF16, U8 = 0, 1, 2, 3
 EPI_SILU, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4
 
 
@@ -77,6 +77,9 @@ SIGNATURES = {
     "sy11_stft_logmel": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "sy11_stft_minmax_init": [_i32, _vp, _vp],
     "sy11_stft_normalize": [_i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "sy11_image_u8_to_float": [_i32, C.c_int64, _vp, _vp, _vp],
+    "sy11_image_resize_bilinear": [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "sy11_image_letterbox": [_i32] * 12 + [_vp, _vp, _vp],
 }
 OTHER = {"sy11_version": ([], C.c_int), "sy11_last_error": ([], C.c_char_p),
          "sy11_nms_workspace_bytes": ([_i32], C.c_size_t)}

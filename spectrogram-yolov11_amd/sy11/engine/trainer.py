@@ -5,6 +5,7 @@ Dataset / callbacks / checkpoints / validation loops are outside the hot path (S
 from __future__ import annotations
 
 import math
+import random
 from types import SimpleNamespace
 
 import torch
@@ -14,7 +15,7 @@ from ..utils.torch_utils import ModelEMA
 from . import ddp
 
 DEFAULTS = dict(lr0=0.01, momentum=0.937, weight_decay=0.0005, nbs=64, box=7.5, cls=0.5, dfl=1.5, amp=True,
-                optimizer="SGD", warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1)
+                optimizer="SGD", warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, multi_scale=False, imgsz=640)
 
 
 class DetectionTrainer:
@@ -167,8 +168,23 @@ class DetectionTrainer:
             shape = (iq.shape[0], 3, self.producer.n_mel, self.producer.n_frames)
             batch["img"] = self.producer(iq, out=graph_static_input(self.model, shape) if self.model.training else None)
         else:
+            from . import graph_static_input
+            from .. import ops as K
             img = batch["img"].to(self.device, non_blocking=True)
-            batch["img"] = img.float() / 255 if img.dtype == torch.uint8 else img.float()
+            size = tuple(img.shape[2:])
+            if self.args.multi_scale:                          # train.py:60-73: the size draw, then one resize launch
+                stride = int(max(self.model.stride))
+                sz = random.randrange(int(self.args.imgsz * 0.5), int(self.args.imgsz * 1.5 + stride)) // stride * stride
+                sf = sz / max(size)
+                if sf != 1:
+                    size = tuple(math.ceil(x * sf / stride) * stride for x in size)
+            static = graph_static_input(self.model, (img.shape[0], img.shape[1], *size)) if self.model.training else None
+            if size != tuple(img.shape[2:]):
+                batch["img"] = K.image_resize_bilinear(img.contiguous(), size, dtype=torch.float32, out=static)
+            elif img.dtype == torch.uint8:
+                batch["img"] = K.image_u8_to_float(img.contiguous(), torch.float32, out=static)
+            else:
+                batch["img"] = img.float()
         return batch
 
     def optimizer_step(self):

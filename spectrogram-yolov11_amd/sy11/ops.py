@@ -315,6 +315,50 @@ def stft_normalize(db, mm, out=None):
     return img
 
 
+# ------------------------------------------------------------------------------------------------ image side of preprocess
+def _img_dt(t):
+    return _lib.U8 if t.dtype == torch.uint8 else _DT[t.dtype]
+
+
+def image_u8_to_float(x, dtype=torch.float32, out=None):
+    """batch["img"].float() / 255 (models/yolo/detect/train.py:59) in one pass; `out` may be a graph's static input."""
+    if x.dtype != torch.uint8 or not x.is_contiguous():
+        raise _lib.Sy11Error("image_u8_to_float: x must be a contiguous uint8 tensor")
+    y = out if out is not None else torch.empty(x.shape, dtype=dtype, device=x.device)
+    if tuple(y.shape) != tuple(x.shape) or not y.is_contiguous() or y.device != x.device:
+        raise _lib.Sy11Error("image_u8_to_float: `out` must be a contiguous tensor of x's shape on x's device")
+    call("sy11_image_u8_to_float", _DT[y.dtype], x.numel(), _p(x), _p(y), _stream())
+    return y
+
+
+def image_resize_bilinear(x, size, dtype=None, out=None):
+    """F.interpolate(x, size=size, mode="bilinear", align_corners=False) on (B, C, H, W); a uint8 x is divided by 255
+    first (the multi_scale branch of preprocess_batch, models/yolo/detect/train.py:60-73)."""
+    if x.dim() != 4 or not x.is_contiguous():
+        raise _lib.Sy11Error("image_resize_bilinear: x must be a contiguous (B, C, H, W) tensor")
+    B, Cc, IH, IW = x.shape
+    OH, OW = int(size[0]), int(size[1])
+    dtype = dtype or (torch.float32 if x.dtype == torch.uint8 else x.dtype)
+    y = out if out is not None else torch.empty((B, Cc, OH, OW), dtype=dtype, device=x.device)
+    if tuple(y.shape) != (B, Cc, OH, OW) or not y.is_contiguous() or y.device != x.device:
+        raise _lib.Sy11Error("image_resize_bilinear: `out` must be a contiguous (B, C, OH, OW) tensor on x's device")
+    call("sy11_image_resize_bilinear", _img_dt(x), _DT[y.dtype], B * Cc, IH, IW, OH, OW, _p(x), _p(y), _stream())
+    return y
+
+
+def image_letterbox(src, dst, new_hw, top, left, fill=114, reverse_c=False, chw=True):
+    """src (h, w, 3) uint8 HWC on the device -> dst: a (3, H, W) / (H, W, 3) uint8 or float tensor (one batch slot).
+    LetterBox.__call__ (data/augment.py:1544-1591) + the BGR->RGB / HWC->CHW / /255 of predictor.preprocess."""
+    if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3 or not src.is_contiguous():
+        raise _lib.Sy11Error("image_letterbox: src must be a contiguous (h, w, 3) uint8 tensor")
+    if dst.dim() != 3 or not dst.is_contiguous() or dst.device != src.device or dst.shape[0 if chw else 2] != 3:
+        raise _lib.Sy11Error("image_letterbox: dst must be a contiguous (3, H, W) [chw] or (H, W, 3) tensor on src's device")
+    H, W = (dst.shape[1], dst.shape[2]) if chw else (dst.shape[0], dst.shape[1])
+    call("sy11_image_letterbox", _img_dt(dst), src.shape[0], src.shape[1], H, W, int(new_hw[0]), int(new_hw[1]), int(top),
+         int(left), int(fill), int(bool(reverse_c)), int(bool(chw)), _p(src), _p(dst), _stream())
+    return dst
+
+
 class DetLossWorkspace:
     """Device buffers of one fused-loss evaluation (kept for the backward launch)."""
 
