@@ -257,6 +257,21 @@ int sy11_image_resize_bilinear(int32_t x_dtype, int32_t y_dtype, int32_t planes,
 int sy11_image_letterbox(int32_t dtype, int32_t sh, int32_t sw, int32_t H, int32_t W, int32_t new_h, int32_t new_w,
                          int32_t top, int32_t left, int32_t fill, int32_t reverse_c, int32_t chw,
                          const uint8_t* src, void* dst, void* stream);
+/* One training sample of the augmentation pipeline in a single launch (data/augment.py: Mosaic._mosaic4 :660-715 then
+ * RandomPerspective.affine_transform :1000-1078 then RandomHSV :1303-1390 then RandomFlip :1393-1474 then the
+ * transpose / channel flip of Format._format_img :2070-2107).  The mosaic canvas (canvas_h x canvas_w filled with
+ * `fill`) is virtual: tile t (tile_src[t] = device pointer to an (h w 3) uint8 image) covers canvas
+ * [x1 x2) x [y1 y2) and canvas pixel (x y) reads source pixel (x - padw  y - padh); tile_geom holds 8 int32 per
+ * tile in the order h w x1 y1 x2 y2 padw padh.  minv = the 6 doubles of the INVERTED 2x3 map exactly as
+ * cv::warpAffine computes them (NULL: no warp and the output is the canvas); hsv_lut = 768 bytes hue|sat|val
+ * tables (NULL: no HSV step).  tile_src / tile_geom / minv / hsv_lut are HOST arrays (copied into the launch).
+ * Output H x W written as with sy11_image_letterbox (dtype SY11_U8 or float / 255; chw; reverse_c).
+ * cv2.warpAffine and cv2.cvtColor are restated from OpenCV 4.x (imgwarp.cpp fixed-point INTER_LINEAR path;
+ * color_hsv.simd.hpp RGB2HSV_b / HSV2RGB_b): opencv-python is an un-vendored reference dependency              */
+int sy11_image_mosaic_warp(int32_t dtype, int32_t n_tiles, const uint8_t* const* tile_src, const int32_t* tile_geom,
+                           int32_t canvas_h, int32_t canvas_w, const double* minv, int32_t H, int32_t W,
+                           const uint8_t* hsv_lut, int32_t flip_ud, int32_t flip_lr, int32_t fill,
+                           int32_t reverse_c, int32_t chw, void* dst, void* stream);
 
 #ifdef __cplusplus
 }

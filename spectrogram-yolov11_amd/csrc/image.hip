@@ -11,6 +11,7 @@
 // resize follows OpenCV's published 8-bit INTER_LINEAR algorithm (imgproc/src/resize.cpp: 11-bit coefficients, the
 // ((b*(S>>4))>>16 ... +2)>>2 vertical pass, and the exact-2x INTER_AREA shortcut).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -136,6 +137,142 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const LbArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- mosaic + affine + HSV + flip
+// One launch renders a training sample: the (virtual) mosaic canvas is never materialised — every bilinear tap of
+// cv2.warpAffine looks up which tile covers that canvas pixel — then RandomHSV's BGR->HSV->LUT->BGR and the two flips are
+// applied in registers and the pixel is written once, already in the layout / dtype the batch tensor wants.
+//   Mosaic._mosaic4         data/augment.py:660-715     tiles pasted on a 2s x 2s canvas filled with 114
+//   RandomPerspective       data/augment.py:1000-1078   cv2.warpAffine(img, M[:2], dsize, borderValue=(114,114,114))
+//   RandomHSV               data/augment.py:1303-1390   cv2.cvtColor(BGR2HSV) + 3 LUTs + cv2.cvtColor(HSV2BGR)
+//   RandomFlip              data/augment.py:1393-1474   np.flipud / np.fliplr
+// warpAffine follows OpenCV 4.x imgwarp.cpp's fixed-point path: source coordinates in 1/1024 px from
+// rint(M*x*1024) tables, +16, >>5 -> 5 fractional bits that index a bilinear table of exact integer weights
+// (32-fy)(32-fx)*32 ... (sum 32768), result (sum + 16384) >> 15, every tap outside the source = borderValue.
+// cvtColor follows color_hsv.simd.hpp: integer RGB2HSV_b with the 12-bit division tables; float HSV2RGB_b.
+struct WarpTile {
+  const uint8_t* src;
+  int h, w, x1, y1, x2, y2, padw, padh;
+};
+struct WarpArgs {
+  WarpTile tile[4];
+  double m[6];
+  void* dst;
+  int n_tiles, canvas_h, canvas_w, has_warp, H, W, has_hsv, flip_ud, flip_lr, fill, reverse_c, chw;
+  unsigned lut[192];   // 3 x 256 bytes: hue, sat, val
+};
+
+__device__ __forceinline__ double nofma(double x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float nofma(float x) { asm volatile("" : "+v"(x)); return x; }
+
+__device__ __forceinline__ void canvas_fetch(const WarpArgs& a, int cx, int cy, int* v) {
+  v[0] = v[1] = v[2] = a.fill;
+  if ((unsigned)cx >= (unsigned)a.canvas_w || (unsigned)cy >= (unsigned)a.canvas_h) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < a.n_tiles) {
+      const WarpTile& k = a.tile[t];
+      if (cx >= k.x1 && cx < k.x2 && cy >= k.y1 && cy < k.y2) {
+        const uint8_t* p = k.src + ((long)(cy - k.padh) * k.w + (cx - k.padw)) * 3;
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mosaic_warp_kernel(const WarpArgs a) {
+  __shared__ unsigned lut32[192];
+  if (a.has_hsv) {
+    if (threadIdx.x < 192) lut32[threadIdx.x] = a.lut[threadIdx.x];
+    __syncthreads();
+  }
+  const uint8_t* lut = (const uint8_t*)lut32;
+  const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+  if (X >= a.W) return;
+  const int wx = a.flip_lr ? a.W - 1 - X : X, wy = a.flip_ud ? a.H - 1 - Y : Y;
+  int v[3];
+  if (a.has_warp) {
+    const int adelta = __double2int_rn(a.m[0] * (double)wx * 1024.0), bdelta = __double2int_rn(a.m[3] * (double)wx * 1024.0);
+    const int X0 = __double2int_rn((nofma(a.m[1] * (double)wy) + a.m[2]) * 1024.0) + 16;
+    const int Y0 = __double2int_rn((nofma(a.m[4] * (double)wy) + a.m[5]) * 1024.0) + 16;
+    const int Xf = (X0 + adelta) >> 5, Yf = (Y0 + bdelta) >> 5;
+    int sx = Xf >> 5, sy = Yf >> 5;
+    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);      // saturate_cast<short>
+    sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+    const int fx = Xf & 31, fy = Yf & 31;
+    const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    int t00[3], t01[3], t10[3], t11[3];
+    canvas_fetch(a, sx, sy, t00);
+    canvas_fetch(a, sx + 1, sy, t01);
+    canvas_fetch(a, sx, sy + 1, t10);
+    canvas_fetch(a, sx + 1, sy + 1, t11);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int r = (t00[c] * w00 + t01[c] * w01 + t10[c] * w10 + t11[c] * w11 + 16384) >> 15;
+      v[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
+    }
+  } else {
+    canvas_fetch(a, wx, wy, v);
+  }
+  if (a.has_hsv) {
+    const int b = v[0], g = v[1], r = v[2];
+    const int vmax = max(max(b, g), r), vmin = min(min(b, g), r), diff = vmax - vmin;
+    // hdiv_table180[i] = cvRound((180 << 12) / (6. * i)); sdiv_table[i] = cvRound((255 << 12) / (1. * i)); [0] = 0
+    const int sdiv = vmax ? __double2int_rn(1044480.0 / (double)vmax) : 0;
+    const int hdiv = diff ? __double2int_rn(737280.0 / (6.0 * (double)diff)) : 0;
+    int s = (diff * sdiv + 2048) >> 12;
+    int h = vmax == r ? g - b : (vmax == g ? b - r + 2 * diff : r - g + 4 * diff);
+    h = (h * hdiv + 2048) >> 12;
+    h += h < 0 ? 180 : 0;
+    h = h > 255 ? 255 : h;
+    const int h2 = lut[h], s2 = lut[256 + (s & 255)], v2 = lut[512 + vmax];
+    // HSV2RGB_b: floats, hscale = 6/180
+    const float fs = (float)s2 * (1.f / 255.f), fv = (float)v2 * (1.f / 255.f);
+    float fb = fv, fg = fv, fr = fv;
+    if (s2 != 0) {
+      float hh = nofma((float)h2 * (6.f / 180.f));        // keep the product rounded: hh - sector must not become an fma
+      int sector = (int)floorf(hh);
+      hh -= (float)sector;
+      if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }
+      const float t1 = fv * (1.f - fs);
+      const float t2 = fv * (1.f - nofma(fs * hh));
+      const float t3 = fv * (1.f - nofma(fs * (1.f - hh)));
+      // sector_data = {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} -> (b, g, r) picks from tab = {v, t1, t2, t3}
+      switch (sector) {
+        case 0: fb = t1; fg = t3; fr = fv; break;
+        case 1: fb = t1; fg = fv; fr = t2; break;
+        case 2: fb = t3; fg = fv; fr = t1; break;
+        case 3: fb = fv; fg = t2; fr = t1; break;
+        case 4: fb = fv; fg = t1; fr = t3; break;
+        default: fb = t2; fg = t1; fr = fv; break;
+      }
+    }
+    const int ob = __float2int_rn(fb * 255.f), og = __float2int_rn(fg * 255.f), orr = __float2int_rn(fr * 255.f);
+    v[0] = ob < 0 ? 0 : (ob > 255 ? 255 : ob);
+    v[1] = og < 0 ? 0 : (og > 255 ? 255 : og);
+    v[2] = orr < 0 ? 0 : (orr > 255 ? 255 : orr);
+  }
+  if (a.reverse_c) { const int t = v[0]; v[0] = v[2]; v[2] = t; }
+  if constexpr (sizeof(T) == 1) {
+    uint8_t* d = (uint8_t*)a.dst;
+    if (a.chw) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d[((long)c * a.H + Y) * a.W + X] = (uint8_t)v[c];
+    } else {
+      uint8_t* p = d + ((long)Y * a.W + X) * 3;
+      p[0] = (uint8_t)v[0]; p[1] = (uint8_t)v[1]; p[2] = (uint8_t)v[2];
+    }
+  } else {
+    T* d = (T*)a.dst;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const T o = Out<T>::cvt(__fdiv_rn((float)v[c], 255.0f));
+      if (a.chw) d[((long)c * a.H + Y) * a.W + X] = o;
+      else d[((long)Y * a.W + X) * 3 + c] = o;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int sy11_image_u8_to_float(int32_t dtype, int64_t n, const uint8_t* x, void* y, void* stream) {
@@ -198,5 +335,43 @@ extern "C" int sy11_image_letterbox(int32_t dtype, int32_t sh, int32_t sw, int32
   else if (dtype == SY11_F16) letterbox_kernel<_Float16><<<grid, 256, 0, s>>>(a);
   else letterbox_kernel<__bf16><<<grid, 256, 0, s>>>(a);
   SY11_LAUNCH_CHECK("image_letterbox");
+  return SY11_OK;
+}
+
+extern "C" int sy11_image_mosaic_warp(int32_t dtype, int32_t n_tiles, const uint8_t* const* tile_src, const int32_t* tile_geom,
+                                      int32_t canvas_h, int32_t canvas_w, const double* minv, int32_t H, int32_t W,
+                                      const uint8_t* hsv_lut, int32_t flip_ud, int32_t flip_lr, int32_t fill,
+                                      int32_t reverse_c, int32_t chw, void* dst, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) || dtype == SY11_U8, "image_mosaic_warp: bad dtype %d", dtype);
+  SY11_REQUIRE(n_tiles >= 0 && n_tiles <= 4 && (n_tiles == 0 || (tile_src && tile_geom)), "image_mosaic_warp: 0..4 tiles");
+  SY11_REQUIRE(canvas_h > 0 && canvas_w > 0 && H > 0 && W > 0 && H <= 65535 && dst, "image_mosaic_warp: bad shape");
+  SY11_REQUIRE(minv || (H == canvas_h && W == canvas_w), "image_mosaic_warp: without a warp the output is the canvas (%d x %d)", canvas_h, canvas_w);
+  SY11_REQUIRE(fill >= 0 && fill <= 255, "image_mosaic_warp: fill must be a byte");
+  WarpArgs a;
+  for (int t = 0; t < 4; ++t) a.tile[t] = WarpTile{nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < n_tiles; ++t) {
+    const int32_t* g = tile_geom + 8 * t;
+    WarpTile k{tile_src[t], g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]};
+    SY11_REQUIRE(k.src && k.h > 0 && k.w > 0, "image_mosaic_warp: tile %d has no pixels", t);
+    SY11_REQUIRE(k.x1 >= 0 && k.y1 >= 0 && k.x2 <= canvas_w && k.y2 <= canvas_h && k.x1 <= k.x2 && k.y1 <= k.y2,
+                 "image_mosaic_warp: tile %d region [%d,%d)x[%d,%d) leaves the %d x %d canvas", t, k.x1, k.x2, k.y1, k.y2, canvas_w, canvas_h);
+    SY11_REQUIRE(k.x1 - k.padw >= 0 && k.x2 - k.padw <= k.w && k.y1 - k.padh >= 0 && k.y2 - k.padh <= k.h,
+                 "image_mosaic_warp: tile %d region reads outside its %d x %d source", t, k.h, k.w);
+    a.tile[t] = k;
+  }
+  a.n_tiles = n_tiles; a.canvas_h = canvas_h; a.canvas_w = canvas_w; a.H = H; a.W = W; a.dst = dst;
+  a.has_warp = minv ? 1 : 0;
+  for (int i = 0; i < 6; ++i) a.m[i] = minv ? minv[i] : 0.0;
+  a.has_hsv = hsv_lut ? 1 : 0;
+  if (hsv_lut) memcpy(a.lut, hsv_lut, 768);
+  else memset(a.lut, 0, 768);
+  a.flip_ud = flip_ud; a.flip_lr = flip_lr; a.fill = fill; a.reverse_c = reverse_c; a.chw = chw;
+  const dim3 grid(cdiv(W, 256), H);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SY11_U8) mosaic_warp_kernel<uint8_t><<<grid, 256, 0, s>>>(a);
+  else if (dtype == SY11_F32) mosaic_warp_kernel<float><<<grid, 256, 0, s>>>(a);
+  else if (dtype == SY11_F16) mosaic_warp_kernel<_Float16><<<grid, 256, 0, s>>>(a);
+  else mosaic_warp_kernel<__bf16><<<grid, 256, 0, s>>>(a);
+  SY11_LAUNCH_CHECK("image_mosaic_warp");
   return SY11_OK;
 }

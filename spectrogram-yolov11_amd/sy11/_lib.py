@@ -80,6 +80,7 @@ SIGNATURES = {
     "sy11_image_u8_to_float": [_i32, C.c_int64, _vp, _vp, _vp],
     "sy11_image_resize_bilinear": [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "sy11_image_letterbox": [_i32] * 12 + [_vp, _vp, _vp],
+    "sy11_image_mosaic_warp": [_i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
 }
 OTHER = {"sy11_version": ([], C.c_int), "sy11_last_error": ([], C.c_char_p),
          "sy11_nms_workspace_bytes": ([_i32], C.c_size_t)}

@@ -1,0 +1,371 @@
+"""Detection dataset + loader of the data path with the reference's names (ultralytics/data/base.py BaseDataset :22-346,
+data/dataset.py YOLODataset :46-248, data/build.py :30-157, data/utils.py img2label_paths :44-47 and the label rules
+of verify_image_label :100-165), cut for the MI355X:
+
+  * the host only DECODES (np.load for .npy spectrograms / caches, PIL for image files — the reference's cv2.imread is
+    not available here) and keeps the label arithmetic;
+  * every pixel operation of load_image / LetterBox / Mosaic / RandomPerspective / RandomHSV / RandomFlip / Format
+    happens on the GPU: the raw image is uploaded once, ``load_image``'s long-side resize is one launch, and the whole
+    augmentation chain of a sample is ONE launch that writes into that sample's slot of the batch tensor
+    (``collate_fn`` allocates the batch, or fills a caller-provided static input, and renders the deferred images).
+
+Because the samples hold device tensors the loader runs in the training process (no worker processes to pickle
+through); file decoding for the next batch overlaps through a small thread pool."""
+from __future__ import annotations
+
+import glob
+import math
+import os
+import random
+from concurrent.futures import ThreadPoolExecutor
+from copy import deepcopy
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .. import ops as K
+from ..utils.instance import Instances
+from .augment import Compose, DeviceImage, Format, LetterBox, v8_transforms
+
+IMG_FORMATS = {"bmp", "dng", "jpeg", "jpg", "mpo", "png", "tif", "tiff", "webp", "pfm", "heic", "npy"}   # data/utils.py:38 + raw .npy
+# cfg/default.yaml augmentation block
+DEFAULT_HYP = dict(hsv_h=0.015, hsv_s=0.7, hsv_v=0.4, degrees=0.0, translate=0.1, scale=0.5, shear=0.0, perspective=0.0,
+                   flipud=0.0, fliplr=0.5, bgr=0.0, mosaic=1.0, mixup=0.0, copy_paste=0.0, mask_ratio=4, overlap_mask=True)
+
+
+def img2label_paths(img_paths):
+    """data/utils.py:44-47: .../images/x.ext -> .../labels/x.txt (last occurrence of /images/)."""
+    sa, sb = f"{os.sep}images{os.sep}", f"{os.sep}labels{os.sep}"
+    return [sb.join(x.rsplit(sa, 1)).rsplit(".", 1)[0] + ".txt" for x in img_paths]
+
+
+def read_image(path):
+    """Decode to (h, w, 3) uint8 BGR like cv2.imread (base.py:153-165): a sibling / direct .npy wins, else PIL."""
+    p = Path(path)
+    npy = p if p.suffix == ".npy" else p.with_suffix(".npy")
+    if npy.exists():
+        im = np.load(npy)
+    else:
+        from PIL import Image
+        with Image.open(p) as f:
+            im = np.asarray(f.convert("RGB"))[..., ::-1]
+    if im.ndim == 2:
+        im = np.repeat(im[..., None], 3, 2)
+    if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+        raise ValueError(f"{path}: expected an (h, w, 3) uint8 image, got {im.dtype} {im.shape}")
+    return np.ascontiguousarray(im)
+
+
+def image_hw(path):
+    p = Path(path)
+    npy = p if p.suffix == ".npy" else p.with_suffix(".npy")
+    if npy.exists():
+        return tuple(np.load(npy, mmap_mode="r").shape[:2])
+    from PIL import Image
+    with Image.open(p) as f:
+        return (f.size[1], f.size[0])
+
+
+def read_label(path, nc=None):
+    """The checks of verify_image_label (data/utils.py:118-152) for detection: 5 columns, no negatives, normalised
+    coordinates, class < nc, duplicate rows dropped (np.unique order).  Returns (n, 5) float32 [cls, x, y, w, h]."""
+    if not os.path.isfile(path):
+        return np.zeros((0, 5), np.float32)
+    with open(path) as f:
+        rows = [x.split() for x in f.read().strip().splitlines() if len(x)]
+    if any(len(x) > 6 for x in rows):
+        raise NotImplementedError(f"{path}: segment labels are out of scope for the detection data path")
+    lb = np.array(rows, dtype=np.float32)
+    if not len(lb):
+        return np.zeros((0, 5), np.float32)
+    assert lb.shape[1] == 5, f"labels require 5 columns, {lb.shape[1]} columns detected"
+    assert lb[:, 1:].max() <= 1, f"non-normalized or out of bounds coordinates {lb[:, 1:][lb[:, 1:] > 1]}"
+    assert lb.min() >= 0, f"negative label values {lb[lb < 0]}"
+    if nc is not None:
+        assert lb[:, 0].max() < nc, f"Label class {int(lb[:, 0].max())} exceeds dataset class count {nc}."
+    _, i = np.unique(lb, axis=0, return_index=True)
+    if len(i) < len(lb):
+        lb = lb[i]
+    return lb
+
+
+class YOLODataset:
+    """base.py:22-346 + dataset.py:46-248 for task="detect"."""
+
+    def __init__(self, img_path, imgsz=640, cache=False, augment=True, hyp=None, prefix="", rect=False, batch_size=16,
+                 stride=32, pad=0.5, single_cls=False, classes=None, fraction=1.0, data=None, task="detect", device="cuda"):
+        if task != "detect":
+            raise NotImplementedError("sy11 YOLODataset carries the detection task only")
+        self.img_path, self.imgsz, self.augment, self.single_cls = img_path, imgsz, augment, single_cls
+        self.prefix, self.fraction, self.data, self.device = prefix, fraction, data or {}, torch.device(device)
+        self.rect, self.batch_size, self.stride, self.pad = rect, batch_size, stride, pad
+        self.hyp = hyp if hyp is not None else SimpleNamespace(**DEFAULT_HYP)
+        self.im_files = self.get_img_files(img_path)
+        self.labels = self.get_labels()
+        self.update_labels(include_class=classes)
+        self.ni = len(self.labels)
+        if self.rect:
+            assert self.batch_size is not None
+            self.set_rectangle()
+        self.buffer = []                                                    # base.py:77-79
+        self.max_buffer_length = min((self.ni, self.batch_size * 8, 1000)) if self.augment else 0
+        self.ims, self.im_hw0, self.im_hw = [None] * self.ni, [None] * self.ni, [None] * self.ni
+        self._decoding = {}                                                 # index -> Future of a background read_image
+        self.transforms = self.build_transforms(hyp=self.hyp)
+
+    # -- files and labels
+    def get_img_files(self, img_path):
+        f = []
+        for p in img_path if isinstance(img_path, list) else [img_path]:
+            p = Path(p)
+            if p.is_dir():
+                f += glob.glob(str(p / "**" / "*.*"), recursive=True)
+            elif p.is_file():
+                with open(p) as t:
+                    parent = str(p.parent) + os.sep
+                    f += [x.replace("./", parent) if x.startswith("./") else x for x in t.read().strip().splitlines()]
+            else:
+                raise FileNotFoundError(f"{self.prefix}{p} does not exist")
+        files = sorted(x.replace("/", os.sep) for x in f if x.split(".")[-1].lower() in IMG_FORMATS)
+        # an image and its .npy cache are one sample
+        seen, im_files = set(), []
+        for x in files:
+            stem = x.rsplit(".", 1)[0]
+            if stem not in seen:
+                seen.add(stem)
+                im_files.append(x)
+        if not im_files:
+            raise FileNotFoundError(f"{self.prefix}No images found in {img_path}")
+        if self.fraction < 1:
+            im_files = im_files[: round(len(im_files) * self.fraction)]
+        return im_files
+
+    def get_labels(self):
+        nc = len(self.data["names"]) if "names" in self.data else self.data.get("nc")
+        labels = []
+        for im_file, lb_file in zip(self.im_files, img2label_paths(self.im_files)):
+            lb = read_label(lb_file, nc)
+            labels.append({"im_file": im_file, "shape": image_hw(im_file), "cls": lb[:, 0:1], "bboxes": lb[:, 1:],
+                           "normalized": True, "bbox_format": "xywh"})
+        return labels
+
+    def update_labels(self, include_class):
+        """base.py:132-149."""
+        include = np.array(include_class).reshape(1, -1) if include_class is not None else None
+        for lb in self.labels:
+            if include is not None:
+                j = (lb["cls"] == include).any(1)
+                lb["cls"], lb["bboxes"] = lb["cls"][j], lb["bboxes"][j]
+            if self.single_cls:
+                lb["cls"][:, 0] = 0
+
+    def set_rectangle(self):
+        """base.py:270-288: sort by aspect ratio, one stride-rounded shape per batch."""
+        bi = np.floor(np.arange(self.ni) / self.batch_size).astype(int)
+        nb = bi[-1] + 1
+        s = np.array([x.pop("shape") for x in self.labels])
+        ar = s[:, 0] / s[:, 1]
+        irect = ar.argsort()
+        self.im_files = [self.im_files[i] for i in irect]
+        self.labels = [self.labels[i] for i in irect]
+        ar = ar[irect]
+        shapes = [[1, 1]] * nb
+        for i in range(nb):
+            ari = ar[bi == i]
+            mini, maxi = ari.min(), ari.max()
+            if maxi < 1:
+                shapes[i] = [maxi, 1]
+            elif mini > 1:
+                shapes[i] = [1, 1 / mini]
+        self.batch_shapes = np.ceil(np.array(shapes) * self.imgsz / self.stride + self.pad).astype(int) * self.stride
+        self.batch = bi
+
+    # -- pixels
+    def load_image(self, i, rect_mode=True):
+        """base.py:151-187: decode, long side -> imgsz (cv2.resize INTER_LINEAR semantics, on the GPU), mosaic buffer."""
+        im = self.ims[i]
+        if im is None:
+            fut = self._decoding.pop(i, None)
+            raw = fut.result() if fut is not None else read_image(self.im_files[i])
+            h0, w0 = raw.shape[:2]
+            src = torch.from_numpy(raw).to(self.device, non_blocking=True) if self.device.type == "cuda" else torch.from_numpy(raw)
+            if rect_mode:
+                r = self.imgsz / max(h0, w0)
+                size = (min(math.ceil(h0 * r), self.imgsz), min(math.ceil(w0 * r), self.imgsz)) if r != 1 else (h0, w0)
+            else:
+                size = (self.imgsz, self.imgsz)
+            if size != (h0, w0):
+                im = torch.empty((*size, 3), dtype=torch.uint8, device=src.device)
+                K.image_letterbox(src, im, size, 0, 0, 114, reverse_c=False, chw=False)
+            else:
+                im = src
+            if self.augment:
+                self.ims[i], self.im_hw0[i], self.im_hw[i] = im, (h0, w0), tuple(im.shape[:2])
+                self.buffer.append(i)
+                if 1 < len(self.buffer) >= self.max_buffer_length:
+                    j = self.buffer.pop(0)
+                    self.ims[j], self.im_hw0[j], self.im_hw[j] = None, None, None
+            return im, (h0, w0), tuple(im.shape[:2])
+        return self.ims[i], self.im_hw0[i], self.im_hw[i]
+
+    def get_image_and_label(self, index):
+        """base.py:290-301 + dataset.py:204-229 (update_labels_info)."""
+        label = deepcopy(self.labels[index])
+        label.pop("shape", None)
+        im, label["ori_shape"], label["resized_shape"] = self.load_image(index)
+        label["img"] = DeviceImage.wrap(im)
+        label["ratio_pad"] = (label["resized_shape"][0] / label["ori_shape"][0], label["resized_shape"][1] / label["ori_shape"][1])
+        if self.rect:
+            label["rect_shape"] = self.batch_shapes[self.batch[index]]
+        bboxes = label.pop("bboxes")
+        label["instances"] = Instances(bboxes, bbox_format=label.pop("bbox_format"), normalized=label.pop("normalized"))
+        return label
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, index):
+        return self.transforms(self.get_image_and_label(index))
+
+    # -- transforms
+    def build_transforms(self, hyp=None):
+        """dataset.py:174-195."""
+        if self.augment:
+            hyp.mosaic = hyp.mosaic if self.augment and not self.rect else 0.0
+            hyp.mixup = hyp.mixup if self.augment and not self.rect else 0.0
+            transforms = v8_transforms(self, self.imgsz, hyp)
+        else:
+            transforms = Compose([LetterBox(new_shape=(self.imgsz, self.imgsz), scaleup=False, device=self.device)])
+        transforms.append(Format(bbox_format="xywh", normalize=True, batch_idx=True, bgr=hyp.bgr if self.augment else 0.0, defer=True))
+        return transforms
+
+    def close_mosaic(self, hyp):
+        """dataset.py:197-202."""
+        hyp.mosaic = 0.0
+        hyp.copy_paste = 0.0
+        hyp.mixup = 0.0
+        self.transforms = self.build_transforms(hyp)
+
+    # -- batches
+    @staticmethod
+    def collate_fn(batch, out=None, dtype=torch.uint8):
+        """dataset.py:231-248, plus the rendering of deferred images: every sample's recipe is executed by one launch
+        straight into slot b of the batch tensor (``out`` — e.g. a captured graph's static input — or a new one; a
+        float dtype also folds preprocess_batch's /255 into the same pass)."""
+        new_batch = {}
+        keys = batch[0].keys()
+        values = list(zip(*[list(b.values()) for b in batch]))
+        for i, k in enumerate(keys):
+            value = values[i]
+            if k == "img":
+                if all(isinstance(v, DeviceImage) for v in value):
+                    H, W = value[0].shape[:2]
+                    if any(v.shape[:2] != (H, W) for v in value):
+                        raise ValueError("collate_fn: images of one batch must share a shape")
+                    if out is not None:
+                        if tuple(out.shape[1:]) != (3, H, W) or out.shape[0] < len(value):
+                            raise ValueError(f"collate_fn: `out` is {tuple(out.shape)}, the batch is {(len(value), 3, H, W)}")
+                        imgs = out[:len(value)]                          # a short last batch fills a prefix of the buffer
+                    else:
+                        imgs = torch.empty((len(value), 3, H, W), dtype=dtype, device=value[0].device)
+                    for b, v in enumerate(value):
+                        v.render(dst=imgs[b], chw=True, reverse_c=v.final_reverse_c)
+                    value = imgs
+                else:
+                    value = torch.stack(value, 0)
+            if k in {"bboxes", "cls"}:
+                value = torch.cat(value, 0)
+            new_batch[k] = value
+        new_batch["batch_idx"] = list(new_batch["batch_idx"])
+        for i in range(len(new_batch["batch_idx"])):
+            new_batch["batch_idx"][i] += i
+        new_batch["batch_idx"] = torch.cat(new_batch["batch_idx"], 0)
+        return new_batch
+
+
+def build_yolo_dataset(cfg, img_path, batch, data, mode="train", rect=False, stride=32, device="cuda"):
+    """data/build.py:104-126."""
+    return YOLODataset(img_path=img_path, imgsz=cfg.imgsz, batch_size=batch, augment=mode == "train", hyp=cfg,
+                       rect=getattr(cfg, "rect", False) or rect, cache=getattr(cfg, "cache", None) or None,
+                       single_cls=getattr(cfg, "single_cls", False) or False, stride=int(stride),
+                       pad=0.0 if mode == "train" else 0.5, prefix=f"{mode}: ", classes=getattr(cfg, "classes", None),
+                       data=data, fraction=getattr(cfg, "fraction", 1.0) if mode == "train" else 1.0, device=device)
+
+
+class InfiniteDataLoader:
+    """data/build.py:30-86 + build_dataloader :129-157, in-process: an endless stream of batches whose order follows the
+    reference's sampler semantics (seeded shuffle per epoch; a strided shard per rank like DistributedSampler, padded by
+    wrap-around so every rank sees the same number of batches).  ``len()`` is the number of batches per epoch."""
+
+    def __init__(self, dataset, batch_size, shuffle=True, rank=-1, world_size=1, seed=0, prefetch=4, out=None, dtype=torch.uint8):
+        self.dataset, self.batch_size, self.shuffle = dataset, min(batch_size, len(dataset)), shuffle
+        self.rank, self.world_size = rank, max(world_size, 1)
+        self.generator = torch.Generator()
+        self.generator.manual_seed(6148914691236517205 + max(rank, 0))        # data/build.py:145-146
+        self.seed, self.epoch = seed, 0
+        self.out, self.dtype = out, dtype
+        self.pool = ThreadPoolExecutor(max_workers=prefetch) if prefetch else None
+        self._it = self._forever()
+
+    def _epoch_indices(self):
+        n = len(self.dataset)
+        if self.rank == -1:
+            return torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        # DistributedSampler: permutation seeded by (seed + epoch), padded to a multiple of world_size, strided shard
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(n, generator=g).tolist()
+        else:
+            idx = list(range(n))
+        total = math.ceil(n / self.world_size) * self.world_size
+        idx += idx[: total - n]
+        return idx[self.rank:total:self.world_size]
+
+    def __len__(self):
+        n = len(self.dataset) if self.rank == -1 else math.ceil(len(self.dataset) / self.world_size)
+        return math.ceil(n / self.batch_size)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _warm(self, indices):
+        """Decode the files of the coming batch in the background (np.load / PIL release the GIL while reading);
+        load_image picks the decoded array up instead of reading the file itself."""
+        if self.pool is not None:
+            ds = self.dataset
+            for i in indices:
+                if ds.ims[i] is None and i not in ds._decoding:
+                    ds._decoding[i] = self.pool.submit(read_image, ds.im_files[i])
+
+    def _forever(self):
+        while True:
+            idx = self._epoch_indices()
+            batches = [idx[i:i + self.batch_size] for i in range(0, len(idx), self.batch_size)]
+            for k, b in enumerate(batches):
+                if k + 1 < len(batches):
+                    self._warm(batches[k + 1])
+                yield self.dataset.collate_fn([self.dataset[i] for i in b], out=self.out, dtype=self.dtype)
+            self.epoch += 1
+
+    def __iter__(self):
+        for _ in range(len(self)):
+            yield next(self._it)
+
+    def reset(self):
+        self._it = self._forever()
+
+
+def seed_worker(worker_id=0):
+    """data/build.py:89-93."""
+    worker_seed = torch.initial_seed() % 2**32
+    np.random.seed(worker_seed)
+    random.seed(worker_seed)
+
+
+def build_dataloader(dataset, batch, workers=8, shuffle=True, rank=-1, world_size=1, out=None, dtype=torch.uint8):
+    """data/build.py:129-157 (workers = decode threads here)."""
+    return InfiniteDataLoader(dataset, batch, shuffle=shuffle, rank=rank, world_size=world_size, prefetch=min(workers, os.cpu_count() or 1),
+                              out=out, dtype=dtype)

@@ -359,6 +359,35 @@ def image_letterbox(src, dst, new_hw, top, left, fill=114, reverse_c=False, chw=
     return dst
 
 
+def image_mosaic_warp(tiles, canvas_hw, dst, minv=None, hsv_lut=None, flip_ud=False, flip_lr=False, fill=114,
+                      reverse_c=False, chw=True):
+    """Render one augmented sample (sy11_image_mosaic_warp).  tiles = [(src (h, w, 3) uint8 device tensor, x1, y1, x2,
+    y2, padw, padh)] (at most 4); minv = 6 floats of the inverted affine map or None; hsv_lut = (3, 256) uint8 numpy
+    array or None; dst = (3, H, W) / (H, W, 3) uint8 or float device tensor."""
+    import numpy as np
+    n = len(tiles)
+    if dst.dim() != 3 or not dst.is_contiguous() or dst.shape[0 if chw else 2] != 3:
+        raise _lib.Sy11Error("image_mosaic_warp: dst must be a contiguous (3, H, W) [chw] or (H, W, 3) tensor")
+    H, W = (dst.shape[1], dst.shape[2]) if chw else (dst.shape[0], dst.shape[1])
+    srcs = (C.c_void_p * max(n, 1))()
+    geom = (C.c_int32 * (8 * max(n, 1)))()
+    for t, (src, x1, y1, x2, y2, padw, padh) in enumerate(tiles):
+        if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3 or not src.is_contiguous() or src.device != dst.device:
+            raise _lib.Sy11Error("image_mosaic_warp: every tile must be a contiguous (h, w, 3) uint8 tensor on dst's device")
+        srcs[t] = src.data_ptr()
+        geom[8 * t:8 * t + 8] = [src.shape[0], src.shape[1], int(x1), int(y1), int(x2), int(y2), int(padw), int(padh)]
+    m = (C.c_double * 6)(*[float(v) for v in minv]) if minv is not None else None
+    lut = None
+    if hsv_lut is not None:
+        lut_np = np.ascontiguousarray(hsv_lut, dtype=np.uint8)
+        if lut_np.size != 768:
+            raise _lib.Sy11Error("image_mosaic_warp: hsv_lut must hold 3 x 256 bytes")
+        lut = lut_np.ctypes.data_as(C.c_void_p)
+    call("sy11_image_mosaic_warp", _img_dt(dst), n, srcs, geom, int(canvas_hw[0]), int(canvas_hw[1]), m, H, W, lut,
+         int(bool(flip_ud)), int(bool(flip_lr)), int(fill), int(bool(reverse_c)), int(bool(chw)), _p(dst), _stream())
+    return dst
+
+
 class DetLossWorkspace:
     """Device buffers of one fused-loss evaluation (kept for the backward launch)."""
 
