@@ -187,10 +187,14 @@ class Format:
         nl = len(instances)
         labels["img"] = self._format_img(img)
         labels["cls"] = torch.from_numpy(cls) if nl else torch.zeros(nl)
-        labels["bboxes"] = torch.from_numpy(instances.bboxes) if nl else torch.zeros((nl, 4))
-        if self.normalize:
-            labels["bboxes"][:, [0, 2]] /= w
-            labels["bboxes"][:, [1, 3]] /= h
+        if nl:
+            b = instances.bboxes
+            if self.normalize:                 # the same float32 divisions as the reference's tensor `/=`, done before wrapping
+                b[:, [0, 2]] /= np.float32(w)
+                b[:, [1, 3]] /= np.float32(h)
+            labels["bboxes"] = torch.from_numpy(b)
+        else:
+            labels["bboxes"] = torch.zeros((nl, 4))
         if self.batch_idx:
             labels["batch_idx"] = torch.zeros(nl)
         return labels

@@ -18,7 +18,6 @@ import math
 import os
 import random
 from concurrent.futures import ThreadPoolExecutor
-from copy import deepcopy
 from pathlib import Path
 from types import SimpleNamespace
 
@@ -212,8 +211,8 @@ class YOLODataset:
 
     def get_image_and_label(self, index):
         """base.py:290-301 + dataset.py:204-229 (update_labels_info)."""
-        label = deepcopy(self.labels[index])
-        label.pop("shape", None)
+        src = self.labels[index]                                            # a flat dict of two small arrays: copy those, share the rest
+        label = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in src.items() if k != "shape"}
         im, label["ori_shape"], label["resized_shape"] = self.load_image(index)
         label["img"] = DeviceImage.wrap(im)
         label["ratio_pad"] = (label["resized_shape"][0] / label["ori_shape"][0], label["resized_shape"][1] / label["ori_shape"][1])
