@@ -296,7 +296,9 @@ def build_yolo_dataset(cfg, img_path, batch, data, mode="train", rect=False, str
 class InfiniteDataLoader:
     """data/build.py:30-86 + build_dataloader :129-157, in-process: an endless stream of batches whose order follows the
     reference's sampler semantics (seeded shuffle per epoch; a strided shard per rank like DistributedSampler, padded by
-    wrap-around so every rank sees the same number of batches).  ``len()`` is the number of batches per epoch."""
+    wrap-around so every rank sees the same number of batches).  ``len()`` is the number of batches per epoch.
+    ``out`` is the batch image buffer to render into: a tensor, None (allocate), or a callable ``n -> tensor | None``
+    evaluated per batch (``DetectionTrainer.batch_buffer``: the captured graph's static input once it exists)."""
 
     def __init__(self, dataset, batch_size, shuffle=True, rank=-1, world_size=1, seed=0, prefetch=4, out=None, dtype=torch.uint8):
         self.dataset, self.batch_size, self.shuffle = dataset, min(batch_size, len(dataset)), shuffle
@@ -346,7 +348,8 @@ class InfiniteDataLoader:
             for k, b in enumerate(batches):
                 if k + 1 < len(batches):
                     self._warm(batches[k + 1])
-                yield self.dataset.collate_fn([self.dataset[i] for i in b], out=self.out, dtype=self.dtype)
+                out = self.out(len(b)) if callable(self.out) else self.out    # e.g. the captured graph's static input, once it exists
+                yield self.dataset.collate_fn([self.dataset[i] for i in b], out=out, dtype=self.dtype)
             self.epoch += 1
 
     def __iter__(self):

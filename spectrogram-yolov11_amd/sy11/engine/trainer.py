@@ -187,6 +187,13 @@ class DetectionTrainer:
                 batch["img"] = img.float()
         return batch
 
+    def batch_buffer(self, imgsz=None):
+        """A ``n -> tensor | None`` for ``build_dataloader(out=...)``: the static input of the captured training graph
+        for n images (None until the graph exists, then the loader renders every sample straight into it)."""
+        from . import graph_static_input
+        size = (imgsz, imgsz) if isinstance(imgsz, int) else tuple(imgsz or (self.args.imgsz, self.args.imgsz))
+        return lambda n: graph_static_input(self.model, (n, 3, *size)) if self.model.training else None
+
     def optimizer_step(self):
         """trainer.py:585-593."""
         if self.flat is not None:

@@ -122,6 +122,30 @@ def test_dataset_train_batches_render_into_static_input(tmp_path):
     assert seen >= 2
 
 
+def test_train_from_files_renders_into_the_graph_input(tmp_path):
+    """files -> dataset -> fused augmentation -> trainer: after graph capture the loader writes the model's static input."""
+    from oracle import yolo11_ref as R
+    from sy11.data.dataset import YOLODataset, build_dataloader
+    from sy11.engine import graph_static_input
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+    root = _write_dataset(tmp_path / "d", n=8, imgsz=128)
+    m = DetectionModel("yolo11n.yaml", nc=2, verbose=False)
+    m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=2)), seed=1))
+    tr = DetectionTrainer(m, batch_size=4, device=DEV, overrides={"amp": False, "nbs": 4, "imgsz": 128}, graphs=True)
+    ds = YOLODataset(str(root / "images"), imgsz=128, augment=True, batch_size=4, data={"nc": 2})
+    random.seed(0); np.random.seed(0)
+    dl = build_dataloader(ds, 4, workers=2, out=tr.batch_buffer(128), dtype=torch.float32)
+    losses, hits = [], 0
+    for epoch in range(4):
+        for batch in dl:
+            static = graph_static_input(tr.model, (4, 3, 128, 128))
+            hits += int(static is not None and batch["img"].data_ptr() == static.data_ptr())
+            batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            losses.append(float(tr.train_step(batch)[0]))
+    assert len(losses) == 8 and all(np.isfinite(losses)) and hits >= 4, (losses, hits)
+
+
 def test_dataset_val_rect_letterbox_matches_oracle(tmp_path):
     from sy11.data.dataset import YOLODataset
     root = _write_dataset(tmp_path / "d", n=5)
