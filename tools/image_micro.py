@@ -77,6 +77,23 @@ def main():
             nb += 1
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"loader           mosaic train pipeline, {nb} batches of {B}: {nb * B / dt:8.0f} img/s ({dt / nb * 1e3:.1f} ms/batch, files on tmpfs/page cache)")
+        # where the host time goes: recipe building (python) vs the render launches
+        samples = []
+        t0 = time.perf_counter()
+        for i in range(256):
+            samples.append(ds[i])
+        t1 = time.perf_counter()
+        for k in range(0, 256, B):
+            ds.collate_fn(samples[k:k + B], out=static, dtype=torch.float32)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        print(f"  host split     recipe {1e6 * (t1 - t0) / 256:6.0f} us/sample   collate+render {1e6 * (t2 - t1) / 256:6.0f} us/sample")
+        import cProfile, pstats, io
+        pr = cProfile.Profile(); pr.enable()
+        for i in range(128):
+            ds[i]
+        pr.disable()
+        buf = io.StringIO(); pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(14)
+        print("\n".join(l[:150] for l in buf.getvalue().splitlines() if l.strip())[:3000])
         # CPU oracle on a few samples: the same chain in numpy
         from oracle import image_ref as IR
         t0 = time.perf_counter(); k = 4
