@@ -43,7 +43,11 @@ class DetectionValidator:
             img = self.producer(img.to(self.device))
         else:
             img = img.to(self.device)
-            img = img.float() / 255 if img.dtype == torch.uint8 else img.float()
+            if img.dtype == torch.uint8:                    # val.py:54-55: one fused pass instead of .float() then / 255
+                from .. import ops as K
+                img = K.image_u8_to_float(img.contiguous())
+            else:
+                img = img.float()
         batch["img"] = img
         for k in ("batch_idx", "cls", "bboxes"):
             batch[k] = batch[k].to(self.device)

@@ -167,6 +167,28 @@ def test_dataset_val_rect_letterbox_matches_oracle(tmp_path):
     assert b["img"].dtype == torch.uint8 and b["img"].shape[0] == 2 and b["img"].is_cuda
 
 
+def test_validator_over_rect_val_loader(tmp_path):
+    """val mode end to end: rect batches from files (uint8, per-batch shapes) -> DetectionValidator -> metric dict; labels
+    are mapped back to native image space through ori_shape / ratio_pad exactly as val.py:108-128 does."""
+    from oracle import yolo11_ref as R
+    from sy11.data.dataset import YOLODataset, build_dataloader
+    from sy11.engine.validator import DetectionValidator
+    from sy11.nn.tasks import DetectionModel
+    root = _write_dataset(tmp_path / "d", n=10, imgsz=128)
+    ds = YOLODataset(str(root / "images"), imgsz=128, augment=False, rect=True, batch_size=4, pad=0.5, stride=32, data={"nc": 2})
+    dl = build_dataloader(ds, 4, workers=0, shuffle=False)
+    batches = list(dl)
+    assert len(batches) == 3 and all(b["img"].dtype == torch.uint8 and b["img"].is_cuda for b in batches)
+    assert len({tuple(b["img"].shape[2:]) for b in batches}) >= 2                          # rect: shapes differ per batch
+    b0 = batches[0]
+    assert len(b0["ori_shape"]) == b0["img"].shape[0] and len(b0["ratio_pad"][0]) == 2    # ((rh, rw), (padw, padh))
+    m = DetectionModel("yolo11n.yaml", nc=2, verbose=False)
+    m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=2)), seed=1))
+    v = DetectionValidator(m, device=DEV)
+    stats = v(m, batches)
+    assert isinstance(stats, dict) and stats and all(np.isfinite(float(x)) for x in stats.values())
+
+
 def test_mosaic_warp_rejects_bad_arguments():
     from sy11 import _lib, ops as K
     src = torch.zeros((8, 8, 3), dtype=torch.uint8, device=DEV)
