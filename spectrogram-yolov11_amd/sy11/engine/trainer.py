@@ -49,6 +49,8 @@ class DetectionTrainer:
             from . import GradStore
             from .flat import FlatEMA, FlatState
             self.flat = FlatState(self.model)
+            if world_size > 1:                               # DDP's constructor: rank-0 weights and buffers to everybody,
+                ddp.broadcast_parameters(self.model)         # before the EMA takes its copy
             store = GradStore(self.model, order=self.flat.order)
             store.external_zero = True
             store.begin_backward(self.device)
@@ -61,10 +63,11 @@ class DetectionTrainer:
                                                        self.args.momentum, wd)
             self.ema = FlatEMA(self.model, self.flat)
         else:
+            if world_size > 1:
+                ddp.broadcast_parameters(self.model)
             self.optimizer = self.build_optimizer(self.model, self.args.optimizer, self.args.lr0, self.args.momentum, wd)
             self.ema = ModelEMA(self.model)
         if world_size > 1:
-            ddp.broadcast_parameters(self.model)
             ddp.attach(self.model)
         if graphs:                                          # hipGraph replay of forward/backward after 2 eager steps
             from . import enable_graphs
