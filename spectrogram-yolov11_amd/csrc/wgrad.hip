@@ -183,14 +183,19 @@ template <> struct Mma16<__bf16> {
   }
 };
 
-template <typename T, int TILE>
+// PSPLIT (TILE = 64 only): instead of giving each wave a quarter of the output tile, every wave owns the WHOLE 64 x 64 tile
+// for a quarter of the pixels of each stage (k-step = wave).  Per stage the block then reads each operand fragment from LDS
+// once instead of twice (16 KB instead of 32 KB for the same 16 MFMAs): the tile is LDS-read bound, not MFMA bound.  The
+// four partial tiles are folded through the (then free) staging buffers: wave w keeps fragment w and parks its other three.
+template <typename T, int TILE, bool PSPLIT = false>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
+  static_assert(!PSPLIT || TILE == 64, "PSPLIT is the 64-wide variant");
   constexpr int BP = 64;                          // pixels per stage (4 MFMA k-steps of 16)
   constexpr int ROWB = TILE * 2 + 64;             // LDS row stride in bytes
   constexpr int CPR = TILE / 8;                   // 16-byte chunks per tile row
   constexpr int RPP = 256 / CPR;                  // pixel rows per pass
   constexpr int NPASS = BP / RPP;
-  constexpr int FI = TILE / 64;
+  constexpr int FI = PSPLIT ? TILE / 32 : TILE / 64;
   constexpr int OPB = BP * ROWB;                  // bytes of one operand tile
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * OPB];
 
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
     for (int j = 0; j < FI; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = PSPLIT ? 0 : wave >> 1, wc = PSPLIT ? 0 : wave & 1;
   const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
   // per-lane byte offset inside an operand tile for k-step 0, first 4 rows: row = 8*(grp>>1) + q, col = 16*(grp&1) + 4*p4
   const int lane_off = ((grp >> 1) * 8 + q) * ROWB + ((grp & 1) * 16 + p4 * 4) * 2;
@@ -290,7 +295,8 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
     if (more) load_stage(m_begin + (s + 1) * BP);
     const unsigned char* sd = smem + (s & 1) * 2 * OPB;
 #pragma unroll
-    for (int ks = 0; ks < BP / 16; ++ks) {
+    for (int kq = 0; kq < (PSPLIT ? 1 : BP / 16); ++kq) {
+      const int ks = PSPLIT ? wave : kq;
       s16x8 fa[FI], fb[FI];
 #pragma unroll
       for (int i = 0; i < FI; ++i) {
@@ -315,6 +321,42 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
     __syncthreads();
   }
   const int fcol = lane & 31, fh = lane >> 5;
+  if constexpr (PSPLIT) {
+    // fold the four partial tiles: wave w finishes fragment w = (i, j) = (w >> 1, w & 1); the staging buffers (48 KB, idle
+    // after the last barrier) hold the 3 fragments each wave gives away: [src wave][slot][e][lane] floats, 3 * 4 KB per wave
+    float* red = (float*)smem;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if (f != wave) {
+        const int slot = f - (f > wave ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[((wave * 3 + slot) * 16 + e) * 64 + lane] = acc[f >> 1][f & 1][e];
+      }
+    }
+    __syncthreads();
+    f32x16 tot;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tot[e] = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)                               // select this wave's own fragment without dynamic register indexing
+      if (f == wave) tot = acc[f >> 1][f & 1];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w != wave) {
+        const int slot = wave - (wave > w ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[e] += red[((w * 3 + slot) * 16 + e) * 64 + lane];
+      }
+    }
+    const int fi = wave >> 1, fj = wave & 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = n0 + fi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+      const int k = k0 + fj * 32 + fcol;
+      if (n < a.N && k < a.K) atomicAdd(a.dw + (long)n * a.K + k, tot[e]);
+    }
+    return;
+  }
   if (n0 + TILE <= a.N && k0 + TILE <= a.K) {            // interior tile (the common case): no per-element bounds branches
     float* base = a.dw + (long)(n0 + wr * (TILE / 2) + 4 * fh) * a.K + k0 + wc * (TILE / 2) + fcol;
 #pragma unroll
@@ -338,13 +380,30 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
 }
 
 
-// cfg = 3 * (tile == 128) + {0: ~256, 1: ~512, 2: ~1024 workgroups}
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+// cfg = 4 * kind + r.  kind 0: 64-wide tile, 1: 128-wide tile, 2: 64-wide pixel-split variant (16-bit only); r = 0..3:
+// half a round, one, two, four rounds of resident workgroups.  A "round" = CUs x workgroups that fit one CU (LDS: 2 for
+// the 128-wide tile, 3 for the 64-wide); the pixel-split count is rounded DOWN so the grid never spills a nearly empty
+// extra round (1048 workgroups on 512 slots ran three rounds for two rounds of work).
+constexpr int WGRAD_NCFG = 12;
 static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
-  const int tile = cfg >= 3 ? 128 : 64;
-  const int target_wg = 256 << (cfg % 3);
+  const int kind = cfg >> 2;
+  const bool psplit = kind == 2;
+  const int tile = kind == 1 ? 128 : 64;
+  const int slots = cu_count() * (tile == 128 ? 2 : 3);
+  const int target_wg = (slots << (cfg & 3)) >> 1;
   a.tiles_k = cdiv(a.K, tile);
   const int tiles = a.tiles_k * cdiv(a.N, tile);
-  int splits = cdiv(target_wg, tiles);
+  int splits = target_wg / tiles;
   const int max_splits = cdiv(a.M, 512);               // >= 8 stages of 64 pixels per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -358,10 +417,12 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
     if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<float, 64>), grid, block, 0, st, a);
   } else if (dtype == SY11_F16) {
-    if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 128>), grid, block, 0, st, a);
+    if (psplit) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 64, true>), grid, block, 0, st, a);
+    else if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 128>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad16_kernel<_Float16, 64>), grid, block, 0, st, a);
   } else {
-    if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<__bf16, 128>), grid, block, 0, st, a);
+    if (psplit) hipLaunchKernelGGL((wgrad16_kernel<__bf16, 64, true>), grid, block, 0, st, a);
+    else if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<__bf16, 128>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad16_kernel<__bf16, 64>), grid, block, 0, st, a);
   }
   SY11_LAUNCH_CHECK("conv2d_wgrad");
@@ -411,11 +472,12 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
       a.tap_dy[r * d->KW + s] = (signed char)(r * d->DH - d->PH);
       a.tap_dx[r * d->KW + s] = (signed char)(s * d->DW - d->PW);
     }
-  // static heuristic (r01 sweeps): 128-wide tiles unless the map is small, ~384 workgroups, >= 512 pixels per split
-  int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 3 : 0) + 1;
+  // static heuristic (r01 sweeps): 128-wide tiles unless the map is small, one round of workgroups, >= 512 pixels per split
+  int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 4 : 0) + 1;
   static int forced = -2;
   if (forced == -2) { const char* e = getenv("SY11_WGRAD_CFG"); forced = e ? atoi(e) : -1; }
-  if (forced >= 0 && forced < 6) return wgrad_launch_cfg(a, d->dtype, st, forced);
+  const int ncfg = d->dtype == SY11_F32 ? 8 : WGRAD_NCFG;
+  if (forced >= 0 && forced < ncfg) return wgrad_launch_cfg(a, d->dtype, st, forced);
   if (sy11tune::enabled()) {
     static sy11tune::Cache cache;
     static float* scratch = nullptr;
@@ -435,8 +497,8 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
       if (scratch) {
         WgradArgs t = a;
         t.dw = scratch;
-        const int cands[6] = {0, 1, 2, 3, 4, 5};
-        const int best = sy11tune::pick(cands, 6, [&](int c) { return wgrad_launch_cfg(t, d->dtype, st, c); }, st, "wgrad", key,
+        const int cands[WGRAD_NCFG] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+        const int best = sy11tune::pick(cands, ncfg, [&](int c) { return wgrad_launch_cfg(t, d->dtype, st, c); }, st, "wgrad", key,
                                         (int)(sizeof(key) / sizeof(int)));
         if (best >= 0) { cache.put(h, best); cfg = best; }
       }
