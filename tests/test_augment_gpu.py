@@ -62,6 +62,69 @@ def test_each_step_alone_vs_oracle(seed):
     assert np.array_equal(di.render().cpu().numpy(), want)
 
 
+def test_full_size_sample_vs_oracle_and_properties():
+    """BASELINE size (imgsz 640, 1280 x 1280 canvas): one mosaic sample through the product transforms vs the oracle's
+    sequential numpy chain, plus size-independent properties of the render (identity map, flip involution, tile coverage)."""
+    from types import SimpleNamespace
+    from sy11.data.augment import DeviceImage, Format, v8_transforms
+    from sy11.utils.instance import Instances
+    S = 640
+    g = np.random.default_rng(11)
+    shapes = [(640, 480), (640, 640), (400, 640), (640, 512)]
+    imgs = [g.integers(0, 256, (*sh, 3), dtype=np.uint8) for sh in shapes]
+
+    class DS:
+        data, use_keypoints, buffer = {}, False, [0, 1, 2, 3]
+
+        def __len__(self):
+            return 4
+
+        def get_image_and_label(self, i):
+            h, w = imgs[i].shape[:2]
+            return {"im_file": str(i), "ori_shape": (h, w), "resized_shape": (h, w), "img": DeviceImage.wrap(torch.from_numpy(imgs[i]).to(DEV)),
+                    "cls": np.zeros((1, 1), np.float32), "ratio_pad": (1.0, 1.0),
+                    "instances": Instances(np.array([[0.5, 0.5, 0.3, 0.3]], np.float32))}
+
+    hyp = SimpleNamespace(hsv_h=0.015, hsv_s=0.7, hsv_v=0.4, degrees=7.0, translate=0.1, scale=0.5, shear=1.0, perspective=0.0, flipud=0.5,
+                          fliplr=0.5, bgr=0.0, mosaic=1.0, mixup=0.0, copy_paste=0.0)
+    ds = DS()
+    tf = v8_transforms(ds, S, hyp)
+    tf.append(Format(defer=True))
+    random.seed(5); np.random.seed(5)
+    out = tf(ds.get_image_and_label(0))
+    di = out["img"]
+    got = di.render(chw=True, reverse_c=di.final_reverse_c).cpu().numpy()
+    # oracle: paste -> warpAffine -> HSV -> flips -> CHW / RGB, from the recorded recipe
+    canvas = np.full((2 * S, 2 * S, 3), 114, np.uint8)
+    for t, x1, y1, x2, y2, pw, ph in di.tiles:
+        canvas[y1:y2, x1:x2] = t.cpu().numpy()[y1 - ph:y2 - ph, x1 - pw:x2 - pw]
+    sx, sy, fx, fy = IR.warp_coords(di.minv, S, S)
+    src = canvas.astype(np.int64)
+
+    def tap(xx, yy):
+        inside = (xx >= 0) & (xx < 2 * S) & (yy >= 0) & (yy < 2 * S)
+        return np.where(inside[..., None], src[np.clip(yy, 0, 2 * S - 1), np.clip(xx, 0, 2 * S - 1)], 114)
+
+    w = [((32 - fy) * (32 - fx) * 32)[..., None], ((32 - fy) * fx * 32)[..., None], (fy * (32 - fx) * 32)[..., None], (fy * fx * 32)[..., None]]
+    img = ((tap(sx, sy) * w[0] + tap(sx + 1, sy) * w[1] + tap(sx, sy + 1) * w[2] + tap(sx + 1, sy + 1) * w[3] + 16384) >> 15).astype(np.uint8)
+    hsv = IR.cv2_bgr2hsv_u8(img)
+    img = IR.cv2_hsv2bgr_u8(np.stack((di.lut[0][hsv[..., 0]], di.lut[1][hsv[..., 1]], di.lut[2][hsv[..., 2]]), -1))
+    img = img[::-1] if di.flip_ud else img
+    img = img[:, ::-1] if di.flip_lr else img
+    want = img.transpose(2, 0, 1)
+    want = want[::-1] if di.final_reverse_c else want
+    assert got.shape == (3, S, S) and np.array_equal(got, want)
+    # properties: identity map = the canvas itself; two flips = nothing; every canvas pixel is a tile pixel or 114
+    plain = DeviceImage(di.tiles, di.canvas_hw)
+    base = plain.render().cpu().numpy()
+    assert np.array_equal(base, canvas)
+    ident = DeviceImage(di.tiles, di.canvas_hw).warp(np.array([[1, 0, 0], [0, 1, 0]], np.float32), (2 * S, 2 * S)).render().cpu().numpy()
+    assert np.array_equal(ident, canvas)
+    twice = DeviceImage(di.tiles, di.canvas_hw).flip(ud=True, lr=True).render()
+    back = DeviceImage.wrap(twice).flip(ud=True, lr=True).render().cpu().numpy()
+    assert np.array_equal(back, canvas) and np.array_equal(twice.cpu().numpy(), canvas[::-1, ::-1])
+
+
 def test_full_hsv_cube_vs_oracle():
     """All 2^24 BGR values through BGR->HSV->LUT->BGR in one launch each way of the LUT: integer + float paths bit-exact."""
     from sy11 import ops as K
