@@ -391,7 +391,8 @@ static int cu_count() {
 }
 
 // cfg = 4 * kind + r.  kind 0: 64-wide tile, 1: 128-wide tile, 2: 64-wide pixel-split variant (16-bit only); r = 0..3:
-// half a round, one, two, four rounds of resident workgroups.  A "round" = CUs x workgroups that fit one CU (LDS: 2 for
+// a quarter, half, one, two rounds of resident workgroups (every workgroup ends with tile x tile f32 atomics and the chip
+// adds only ~1.3 TB/s of them: one round of 128-wide tiles is 33.5 MB = 26 us, so small layers want FEWER workgroups).  A "round" = CUs x workgroups that fit one CU (LDS: 2 for
 // the 128-wide tile, 3 for the 64-wide); the pixel-split count is rounded DOWN so the grid never spills a nearly empty
 // extra round (1048 workgroups on 512 slots ran three rounds for two rounds of work).
 constexpr int WGRAD_NCFG = 12;
@@ -400,7 +401,7 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   const bool psplit = kind == 2;
   const int tile = kind == 1 ? 128 : 64;
   const int slots = cu_count() * (tile == 128 ? 2 : 3);
-  const int target_wg = (slots << (cfg & 3)) >> 1;
+  const int target_wg = (slots << (cfg & 3)) >> 2;
   a.tiles_k = cdiv(a.K, tile);
   const int tiles = a.tiles_k * cdiv(a.N, tile);
   int splits = target_wg / tiles;
@@ -473,7 +474,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
       a.tap_dx[r * d->KW + s] = (signed char)(s * d->DW - d->PW);
     }
   // static heuristic (r01 sweeps): 128-wide tiles unless the map is small, one round of workgroups, >= 512 pixels per split
-  int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 4 : 0) + 1;
+  int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 4 : 0) + 2;
   static int forced = -2;
   if (forced == -2) { const char* e = getenv("SY11_WGRAD_CFG"); forced = e ? atoi(e) : -1; }
   const int ncfg = d->dtype == SY11_F32 ? 8 : WGRAD_NCFG;
