@@ -39,6 +39,7 @@ struct IgemmArgs {
   int OHF, OWF, oy_mul, oy_add, ox_mul, ox_add;
   int dense_out;          // 1: output offset is m*y_ld (no decode)
   int tiles_n;
+  int chan_major;     // K loop order: 1 = taps innermost (needs C % stage == 0), 0 = channels innermost
   int stat_slots;
   int stat_stride;        // floats between consecutive stat slots (= channel count of the WHOLE stat row)
   unsigned x_bytes, w_bytes;   // extents of the x / w views in bytes (buffer descriptors range-check against them)
@@ -172,6 +173,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bool simple_k = a.C >= BK;
+  // K order.  Tap-major (all channel slabs of tap 0, then tap 1 ...) re-reads an input pixel after C/BK stages — far beyond
+  // what the 32 KB L1 keeps — so every tap goes to L2 again.  Channel-major (the T taps of one slab back to back) makes the
+  // next stage read the rows the previous one just fetched, shifted by one pixel: most of them are still in L1.
+  const bool chan_major = a.chan_major && a.T > 1 && a.C % BK == 0;
   const bool b_issue = (BN >= RPP) || (wave_u * RPI < BN);         // BN < rows-per-pass: only waves covering real rows issue
   __syncthreads();  // tap tables visible
 
@@ -190,6 +195,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) lds_dma16(sb + i * (RPP * KB), (kvalid && b_off[i] >= 0) ? (unsigned)(b_off[i] + wo) : OOB, wr_);
     }
+    if (chan_major) {                             // all taps of one channel slab back to back (see chan_major above)
+      const bool wrap = kt + 1 >= a.T;
+      kt = wrap ? 0 : kt + 1;
+      kc += wrap ? BK : 0;
+    } else {
     kc += BK;
     if (simple_k) {                               // C >= BK: at most one tap boundary per stage, branch-free
       const bool wrap = kc >= a.C;
@@ -197,6 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
       kt += wrap ? 1 : 0;
     } else {
       while (kc >= a.C) { kc -= a.C; ++kt; }
+    }
     }
   };
 
@@ -550,6 +561,9 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
   if (dbg < 0) { const char* e = getenv("SY11_IGEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
   if (forced == -2) { const char* e = getenv("SY11_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
   a.debug = dbg;
+  static int korder = -1;
+  if (korder < 0) { const char* e = getenv("SY11_IGEMM_KORDER"); korder = e ? atoi(e) : 1; }
+  a.chan_major = korder;
   // static heuristic: widest channel tile the layer fills; small maps (20x20 / 40x40) narrow it until the grid covers the chip
   int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   while (bn > 32 && (long)cdiv(a.M, 128) * cdiv(a.N, bn) < 512) bn >>= 1;
