@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-stft", action="store_true", help="feed resident (B,3,H,W) images instead of IQ")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fwd-leg", action="store_true", help="skip the forward-only (configs[1]) leg reported next to the headline")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel individually instead of hipGraph replay")
     a = ap.parse_args()
 
@@ -157,6 +158,29 @@ def main():
         dt = tmax.item()
     ms = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
+
+    fwd_only = None
+    if rank == 0 and world == 1 and a.mode == "train" and not a.no_fwd_leg:
+        # configs[1] of BASELINE.json, reported next to the headline (never part of `value`): forward only, batch statistics,
+        # resident spectrogram tensors, the same captured graph machinery
+        img = tr.preprocess_batch({**data, **labels})["img"].clone()
+        tr.model.train()
+
+        def fwd():
+            with torch.no_grad():
+                return tr.model(img)
+        for _ in range(3):
+            fwd()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            fwd()
+        torch.cuda.synchronize()
+        fdt = (time.perf_counter() - t1) / a.steps
+        fwd_only = {"workload": "configs[1]: YOLOv11-s forward only, bs=64, resident spectrogram tensors", "value": round(a.batch / fdt, 1),
+                    "unit": "spectrogram-images/s", "ms_per_step": round(fdt * 1e3, 3),
+                    "conv_tflops": round(a.batch / fdt * FWD_GFLOP_PER_IMG / 1e3, 2),
+                    "conv_roofline_frac": round(a.batch / fdt * FWD_GFLOP_PER_IMG / 1e3 / PEAK_TFLOPS[a.dtype], 4)}
 
     roof = None
     if rank == 0 and not a.no_roofline:
@@ -227,7 +251,7 @@ def main():
                        "parallelism": f"dp{world}", "weights": "random-init", "nc": 80},
             "conv_tflops": round(value * gflop / 1e3, 2),
             "conv_roofline_frac": round(value * gflop / 1e3 / PEAK_TFLOPS[a.dtype], 4),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd_only,
         }
         print(json.dumps(out))
     if world > 1:
