@@ -235,6 +235,30 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
 
+    if fwd_only is not None:
+        # the deployed forward: BatchNorm folded into the convs (model.fuse()), eval mode, Detect decode included.  Last thing
+        # this process does with the model (fusing is destructive); reported inside `forward_only`, never part of `value`.
+        from sy11.engine import enable_graphs
+        m = tr.model
+        enable_graphs(m)                                        # fresh entries: the eval forward captures its own graph
+        m.eval()
+        m.fuse()
+
+        def pred():
+            with torch.no_grad():
+                return m(img)
+        for _ in range(3):
+            pred()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            pred()
+        torch.cuda.synchronize()
+        pdt = (time.perf_counter() - t2) / a.steps
+        fwd_only["fused_eval"] = {"workload": "model.fuse() + eval forward incl. Detect decode (predictor path), bs=64", "value": round(a.batch / pdt, 1),
+                                  "ms_per_step": round(pdt * 1e3, 3), "conv_tflops": round(a.batch / pdt * FWD_GFLOP_PER_IMG / 1e3, 2),
+                                  "conv_roofline_frac": round(a.batch / pdt * FWD_GFLOP_PER_IMG / 1e3 / PEAK_TFLOPS[a.dtype], 4)}
+
     if rank == 0:
         gflop = TRAIN_GFLOP_PER_IMG if a.mode == "train" else FWD_GFLOP_PER_IMG
         out = {

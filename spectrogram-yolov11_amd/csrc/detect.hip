@@ -10,59 +10,85 @@
 
 struct DecodeArgs {
   const float* maps[8];
-  int hs[8], ws[8], a0[8];
+  int hs[8], ws[8], a0[8], c0[8];     // c0 = first 64-anchor chunk of the level inside one image
   float strides[8];
-  int B, nc, nl, A;
+  int B, nc, nl, A, chunks;           // chunks = 64-anchor chunks per image
   float* out;
 };
 
+// One workgroup = 64 consecutive anchors of one (image, level).  Their rows (64 x (64 + nc) f32, contiguous in the NHWC map)
+// are staged through LDS with coalesced 16-byte loads — a thread per anchor walking its own 576-byte row touched 64 cache
+// lines per load instruction — then thread (anchor, side) does one DFL expectation and the class sigmoids are written
+// anchor-fastest, which is the reference's (B, 4+nc, A) layout.  Arithmetic and its order are those of the scalar form.
 __global__ __launch_bounds__(256) void detect_decode_kernel(const DecodeArgs a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.B * a.A) return;
-  const int b = idx / a.A, an = idx - b * a.A;
+  extern __shared__ float rows[];                        // [64][no + 1]
+  __shared__ float dist[64][4];
+  const int b = blockIdx.x / a.chunks, ch = blockIdx.x - b * a.chunks;
   int l = 0;
 #pragma unroll
   for (int i = 1; i < 8; ++i)
-    if (i < a.nl && an >= a.a0[i]) l = i;
-  const int loc = an - a.a0[l];
-  const int W = a.ws[l], H = a.hs[l];
-  const int gy = loc / W, gx = loc - gy * W;
-  const int no = 64 + a.nc;
-  const float* src = a.maps[l] + ((long)b * H * W + loc) * no;
-  float d[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
+    if (i < a.nl && ch >= a.c0[i]) l = i;
+  const int W = a.ws[l], HW = a.hs[l] * W;
+  const int loc0 = (ch - a.c0[l]) * 64;
+  const int n_an = min(64, HW - loc0);
+  const int no = 64 + a.nc, ld = no + 1;
+  const float* src = a.maps[l] + ((long)b * HW + loc0) * no;
+  const int total = n_an * no;
+  if ((no & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+    for (int i = threadIdx.x * 4; i < total; i += 1024) {
+      const float4 v = *(const float4*)(src + i);
+      const int r = i / no, c = i - r * no;                // no % 4 == 0: the four values stay in one row
+      float* d = rows + r * ld + c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += 256) { const int r = i / no; rows[r * ld + (i - r * no)] = src[i]; }
+  }
+  __syncthreads();
+  const int an = threadIdx.x & 63, side = threadIdx.x >> 6;
+  if (an < n_an) {
+    const float* v0 = rows + an * ld + side * 16;
     float v[16], mx = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { v[k] = src[s * 16 + k]; mx = fmaxf(mx, v[k]); }
+    for (int k = 0; k < 16; ++k) { v[k] = v0[k]; mx = fmaxf(mx, v[k]); }
     float den = 0.f, num = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const float e = expf(v[k] - mx); den += e; num += e * (float)k; }
-    d[s] = num / den;
+    dist[an][side] = num / den;
   }
-  const float ax = gx + 0.5f, ay = gy + 0.5f, st = a.strides[l];
-  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
-  float* o = a.out + (long)b * (4 + a.nc) * a.A + an;
-  o[0] = (x1 + x2) * 0.5f * st;
-  o[(long)a.A] = (y1 + y2) * 0.5f * st;
-  o[2L * a.A] = (x2 - x1) * st;
-  o[3L * a.A] = (y2 - y1) * st;
-  for (int c = 0; c < a.nc; ++c) o[(long)(4 + c) * a.A] = 1.f / (1.f + expf(-src[64 + c]));
+  __syncthreads();
+  if (an >= n_an) return;
+  const int loc = loc0 + an;
+  float* o = a.out + (long)b * (4 + a.nc) * a.A + a.a0[l] + loc;
+  if (side == 0) {
+    const int gy = loc / W, gx = loc - gy * W;
+    const float ax = gx + 0.5f, ay = gy + 0.5f, st = a.strides[l];
+    const float x1 = ax - dist[an][0], y1 = ay - dist[an][1], x2 = ax + dist[an][2], y2 = ay + dist[an][3];
+    o[0] = (x1 + x2) * 0.5f * st;
+    o[(long)a.A] = (y1 + y2) * 0.5f * st;
+    o[2L * a.A] = (x2 - x1) * st;
+    o[3L * a.A] = (y2 - y1) * st;
+  }
+  const float* cls = rows + an * ld + 64;
+  for (int c = side; c < a.nc; c += 4) o[(long)(4 + c) * a.A] = 1.f / (1.f + expf(-cls[c]));
 }
 
 extern "C" int sy11_detect_decode(int32_t B, int32_t nc, int32_t nl, const float* const* maps, const int32_t* hs,
                                   const int32_t* ws, const float* strides, float* out, void* stream) {
   SY11_REQUIRE(B > 0 && nc > 0 && nl > 0 && nl <= 8 && maps && hs && ws && strides && out, "detect_decode: bad argument");
   DecodeArgs a{};
-  int A = 0;
+  int A = 0, chunks = 0;
   for (int i = 0; i < nl; ++i) {
     SY11_REQUIRE(maps[i] && hs[i] > 0 && ws[i] > 0, "detect_decode: bad level %d", i);
-    a.maps[i] = maps[i]; a.hs[i] = hs[i]; a.ws[i] = ws[i]; a.strides[i] = strides[i]; a.a0[i] = A;
+    a.maps[i] = maps[i]; a.hs[i] = hs[i]; a.ws[i] = ws[i]; a.strides[i] = strides[i]; a.a0[i] = A; a.c0[i] = chunks;
     A += hs[i] * ws[i];
+    chunks += cdiv(hs[i] * ws[i], 64);
   }
-  SY11_REQUIRE((long)B * A < (1L << 31), "detect_decode: too many anchors");
-  a.B = B; a.nc = nc; a.nl = nl; a.A = A; a.out = out;
-  hipLaunchKernelGGL(detect_decode_kernel, dim3(cdiv((long)B * A, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  SY11_REQUIRE((long)B * A < (1L << 31) && (long)B * chunks < (1L << 31), "detect_decode: too many anchors");
+  const size_t lds = (size_t)64 * (64 + nc + 1) * sizeof(float);
+  SY11_REQUIRE(lds <= 60 * 1024, "detect_decode: nc=%d needs %zu bytes of LDS per workgroup (max 61440)", nc, lds);
+  a.B = B; a.nc = nc; a.nl = nl; a.A = A; a.chunks = chunks; a.out = out;
+  hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)(B * chunks)), dim3(256), lds, (hipStream_t)stream, a);
   SY11_LAUNCH_CHECK("detect_decode");
   return SY11_OK;
 }

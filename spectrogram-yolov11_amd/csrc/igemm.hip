@@ -502,7 +502,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
   if (cfg != 3) return true;
   const int epi = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
                   ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
-  return std::is_same<T, _Float16>::value && (epi == 0 || epi == 1 || epi == 8) && a.N > 64 && a.M >= 256;
+  return std::is_same<T, _Float16>::value && (epi == 0 || epi == 1 || epi == 8 || epi == 6) && a.N > 64 && a.M >= 256;   // 6 = the fused inference conv (bias + SiLU)
 }
 
 template <typename T>
@@ -544,6 +544,7 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
     if constexpr (std::is_same<T, _Float16>::value) {
       if (epi_pre == 0) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 0>), grid, block, 0, st, a);
       else if (epi_pre == 1) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 1>), grid, block, 0, st, a);
+      else if (epi_pre == 6) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 6>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 8>), grid, block, 0, st, a);
     }
   } else if (bn == 128) SY11_IG(128, 2, 2);

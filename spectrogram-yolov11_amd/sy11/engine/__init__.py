@@ -370,6 +370,38 @@ class _Graphed:
         torch.cuda.current_stream(dev).wait_stream(side)
 
 
+class _GraphedFwd:
+    """A captured forward-only graph (no tape) for inference / validation / `torch.no_grad()` forwards: the predictor's
+    ~170 launches per batch become one graph launch.  Outputs live in the graph's private pool and are overwritten by the
+    next replay — callers consume them before the next call (postprocess does)."""
+
+    def __init__(self, module, xs, is_list, dtype):
+        dev = xs[0].device
+        self.static_in = [x.detach().clone() for x in xs]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.g_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fwd, stream=side):
+                ec = Ctx(module.training, False, dtype, dev, None, module.__dict__.get("_sy11_pool_hint", 0))
+                ec.capturing = True
+                ec.attach_flat(module)
+                acts = [to_act(t, dtype) for t in self.static_in]
+                out = module._run(ec, acts if is_list else acts[0])
+                if ec.bn_counters:
+                    torch._foreach_add_(ec.bn_counters, 1)
+            outs, _ = _flatten(out)
+            self.static_out = [from_act(a) for a in outs]
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+    def __call__(self, xs):
+        for dst, src in zip(self.static_in, xs):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self.g_fwd.replay()
+        return tuple(o.detach() for o in self.static_out)
+
+
 class GraphFn(torch.autograd.Function):
     """Autograd bridge over a captured pair: copy in, replay forward; copy output grads in, replay backward."""
 
@@ -440,6 +472,18 @@ def run_module(module, x):
         if entry is not None:
             params = [p for p in module.parameters()]
             return GraphFn.apply(entry, len(xs), *xs, *params)
+    elif cfg is not None and not torch.is_grad_enabled():
+        xs, is_list = _flatten(x)
+        dtype = engine_dtype(module)
+        key = (tuple((tuple(t.shape), t.dtype) for t in xs), dtype, "fwd", module.training)
+        entry = cfg["entries"].get(key)
+        if entry is None:
+            n = cfg["seen"].get(key, 0)
+            cfg["seen"][key] = n + 1
+            if n >= cfg["warmup"]:
+                entry = cfg["entries"][key] = _GraphedFwd(module, xs, is_list, dtype)
+        if entry is not None:
+            return entry(xs)
     return _run_module_eager(module, x)
 
 

@@ -57,13 +57,16 @@ class DetectionPredictor:
     """conf / iou / max_det defaults follow cfg/default.yaml (0.25 / 0.7 / 300)."""
 
     def __init__(self, model, device="cuda", conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=False, half=False,
-                 producer=None, imgsz=640):
+                 producer=None, imgsz=640, graphs=True):
         self.device = torch.device(device)
         self.model = model.to(self.device).eval()
         self.model.fuse()                                   # predictor.setup_model -> AutoBackend(fuse=True)
         self.model._sy11_dtype = torch.float16 if half else torch.float32
         self.args = dict(conf=conf, iou=iou, max_det=max_det, classes=classes, agnostic_nms=agnostic_nms)
         self.producer = producer
+        if graphs:                                          # batches of one shape replay a captured forward graph after 2 eager calls
+            from . import enable_graphs
+            enable_graphs(self.model)
         self.imgsz = (imgsz, imgsz) if isinstance(imgsz, int) else tuple(imgsz)
         self._lock = threading.Lock()                       # predictor.py:115: one inference at a time per predictor
 

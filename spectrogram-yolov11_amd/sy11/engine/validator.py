@@ -146,6 +146,9 @@ class DetectionValidator:
         was_training = model.training
         model = model.to(self.device).eval()
         model._sy11_dtype = torch.float16 if self.args["half"] else torch.float32
+        if "_sy11_graph_cfg" not in model.__dict__:          # repeated batch shapes replay a captured forward graph
+            from . import enable_graphs
+            enable_graphs(model)
         self.init_metrics(model)
         for batch in batches:
             batch = self.preprocess(dict(batch))

@@ -98,7 +98,10 @@ class Detect(nn.Module):
             return maps
         if self.reg_max != 16:
             raise ops._lib.Sy11Error("decode kernel assumes reg_max == 16")
-        y = ops.detect_decode([m.data for m in maps], [float(s) for s in self.stride], self.nc)   # (B, 4+nc, A)
+        sf = self.__dict__.get("_stride_host")                 # host copy of the strides: no device read inside a graph capture
+        if sf is None or len(sf) != len(self.stride):
+            sf = self.__dict__["_stride_host"] = [float(v) for v in self.stride.tolist()]
+        y = ops.detect_decode([m.data for m in maps], sf, self.nc)   # (B, 4+nc, A)
         return [_Raw(y)] + maps
 
 

@@ -68,3 +68,25 @@ def test_predict_from_iq():
     pred = DetectionPredictor(m, device=DEV, conf=0.05, producer=SpectrogramProducer(DEV))
     res = pred(S.synthetic_iq(1, seed=4))
     assert len(res) == 1 and res[0].boxes.data.shape[1] == 6
+
+
+def test_forward_graph_replay_is_bit_identical_to_eager():
+    """The predictor's third call on a shape captures a forward-only hipGraph; replays must reproduce the eager result
+    exactly (same kernels, same order), for new inputs too, and a second shape gets its own graph."""
+    from sy11.engine.predictor import DetectionPredictor
+    m, _ = build()
+    eager = DetectionPredictor(m, device=DEV, conf=0.25, iou=0.7, graphs=False)
+    imgs = [R.seeded_image((2, 3, 160, 128), seed=20 + i) for i in range(5)]
+    want = [eager.inference(eager.preprocess(im))[0].clone() for im in imgs]
+    m.__dict__.pop("_sy11_graph_cfg", None)
+    pred = DetectionPredictor(m, device=DEV, conf=0.25, iou=0.7, graphs=True)
+    got = [pred.inference(pred.preprocess(im))[0].clone() for im in imgs]
+    cfg = m.__dict__["_sy11_graph_cfg"]
+    assert len(cfg["entries"]) == 1                                   # calls 3..5 replayed one captured graph
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    other = R.seeded_image((1, 3, 96, 96), seed=3)
+    outs = [pred.inference(pred.preprocess(other))[0].clone() for _ in range(4)]
+    assert len(cfg["entries"]) == 2 and all(torch.equal(outs[0], o) for o in outs[1:])
+    res = pred(imgs[0])
+    assert len(res) == 2
