@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 constexpr int IGEMM_NCFG = 9;
 int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq, int M, int N, int K, int x_ld,
                           int y_ld, int stat_slots, int stat_stride, unsigned x_bytes, unsigned w_bytes, int epi, int nostore, int bn,
-                          hipStream_t st);
+                          hipStream_t st, const float* bias);
 static int epi_code(const IgemmArgs& a) {
   return (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
          ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
@@ -493,7 +493,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
   if (cfg >= 7) {
     const int epi = epi_code(a), bn = cfg == 7 ? 128 : 64;
     if (std::is_same<T, float>::value || a.T != 1 || a.tap_dy[0] || a.tap_dx[0] || a.sy != 1 || a.sx != 1 || !a.dense_out || !a.vec_out) return false;
-    if ((epi != 0 && epi != 1 && epi != 8) || a.K % 32 || a.K != a.C || a.wK != a.K || a.N % 8 || a.debug) return false;
+    if ((epi != 0 && epi != 1 && epi != 8 && epi != 6) || a.K % 32 || a.K != a.C || a.wK != a.K || a.N % 8 || a.debug) return false;
     if (cfg == 7 && a.N <= 64) return false;                 // 128 channels per workgroup only when there are that many
     if (cfg == 8 && a.N <= 32) return false;
     return (size_t)(a.K / 32) * 64 * (bn + 256) + (size_t)128 * bn * 2 <= 150 * 1024;
@@ -509,7 +509,7 @@ template <typename T>
 static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
   if (cfg >= 7)
     return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
-                                 a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st);
+                                 a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st, a.bias);
   const int bm = cfg == 3 ? 256 : 128;
   const int tile = cfg >= 4 ? cfg - 4 : cfg;
   const int bn = tile == 1 ? 64 : (tile == 2 ? 32 : 128);

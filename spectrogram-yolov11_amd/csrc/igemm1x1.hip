@@ -47,9 +47,10 @@ struct P1x1Args {
   int stat_slots, stat_stride;
   unsigned x_bytes, w_bytes;
   int nostore;            // tuner dry run of an accumulating epilogue
+  const float* bias;      // EPI 6: y = silu(acc + bias) — the inference conv with BatchNorm folded in
 };
 
-// EPI: 0 plain store, 1 + BN statistics, 8 accumulate into y
+// EPI: 0 plain store, 1 + BN statistics, 8 accumulate into y, 6 bias + SiLU
 template <typename T, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void igemm1x1p_kernel(const P1x1Args a) {
   constexpr int BM = 128, KB = 64, RPI = 16, RPP = 64;
@@ -118,6 +119,12 @@ __global__ __launch_bounds__(256) void igemm1x1p_kernel(const P1x1Args a) {
     }
   }
   float ssum[NI], ssq[NI];
+  float bias_r[NI];                                    // EPI 6: this lane's output channels never change across tiles
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = bn0 + wn * (BN / WN) + j * 32 + frow;
+    bias_r[j] = (EPI == 6 && n < a.N) ? a.bias[n] : 0.f;
+  }
 #pragma unroll
   for (int j = 0; j < NI; ++j) ssum[j] = ssq[j] = 0.f;
 
@@ -162,7 +169,8 @@ __global__ __launch_bounds__(256) void igemm1x1p_kernel(const P1x1Args a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int cl = wn * (BN / WN) + j * 32 + frow;
-          const float v = acc[i][j][e];
+          float v = acc[i][j][e];
+          if (EPI == 6) v = silu_f(v + bias_r[j]);
           if (EPI & 1) { ssum[j] += v; ssq[j] += v * v; }    // rows >= M and channels >= N are exact zeros (zero-filled operands)
           *(T*)(sT + rl * ROWB + cl * 2) = ElemTraits<T>::from_f(v);
         }
@@ -214,12 +222,12 @@ static size_t p1x1_lds(int bn, int K) { return (size_t)(K / 32) * 64 * (bn + 256
 // returns SY11_EUNSUPPORTED when the problem does not fit this kernel (the caller then uses the generic igemm)
 int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq, int M, int N, int K, int x_ld,
                           int y_ld, int stat_slots, int stat_stride, unsigned x_bytes, unsigned w_bytes, int epi, int nostore, int bn,
-                          hipStream_t st) {
-  if (dtype == SY11_F32 || (epi != 0 && epi != 1 && epi != 8) || K % 32 || K < 32 || N % 8 || (bn != 128 && bn != 64 && bn != 32))
+                          hipStream_t st, const float* bias) {
+  if (dtype == SY11_F32 || (epi != 0 && epi != 1 && epi != 8 && epi != 6) || (epi == 6 && !bias) || K % 32 || K < 32 || N % 8 || (bn != 128 && bn != 64 && bn != 32))
     SY11_FAIL(SY11_EUNSUPPORTED, "igemm1x1p: unsupported problem");
   const size_t lds = p1x1_lds(bn, K);
   if (lds > 150 * 1024) SY11_FAIL(SY11_EUNSUPPORTED, "igemm1x1p: K=%d needs %zu bytes of LDS", K, lds);
-  P1x1Args a{x, w, y, stat_sum, stat_sq, M, N, K, x_ld, y_ld, cdiv(M, 128), stat_slots > 1 ? stat_slots : 1, stat_stride, x_bytes, w_bytes, nostore};
+  P1x1Args a{x, w, y, stat_sum, stat_sq, M, N, K, x_ld, y_ld, cdiv(M, 128), stat_slots > 1 ? stat_slots : 1, stat_stride, x_bytes, w_bytes, nostore, bias};
   const int tiles_n = cdiv(N, bn);
   int gx = a.tiles_m < 256 ? a.tiles_m : 256;
   if (lds <= 72 * 1024 && a.tiles_m >= 1024) gx = 512;       // two resident workgroups per CU when LDS allows
@@ -234,6 +242,7 @@ int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, floa
   do {                                                \
     if (epi == 0) SY11_P1(TT, BNN, WMM, WNN, 0);      \
     else if (epi == 1) SY11_P1(TT, BNN, WMM, WNN, 1); \
+    else if (epi == 6) SY11_P1(TT, BNN, WMM, WNN, 6); \
     else SY11_P1(TT, BNN, WMM, WNN, 8);               \
   } while (0)
 #define SY11_P1T(TT)                              \

@@ -1,5 +1,5 @@
 """Time every distinct convolution of yolo11s (640x640, batch 64, f16) through the C-ABI, per direction, and print the
-multiplicity-weighted totals.  Used to tune tile / split heuristics:  python tools/conv_sweep.py [fwd,dgrad,wgrad] [-v]
+multiplicity-weighted totals.  Used to tune tile / split heuristics:  python tools/conv_sweep.py [fwd,fused,dgrad,wgrad] [-v]
 
 Layer table = (IH, IW, C, N, k, s, groups, count) of the model graph (count = how many layers share the shape)."""
 import sys
@@ -41,7 +41,9 @@ def main():
         dw = torch.zeros(N, k, k, C // g, device="cuda")
         wt = ops.weight_transpose(w) if g == 1 else w
         st = torch.zeros(2, 32, N, device="cuda")
+        bias = torch.zeros(N, device="cuda")
         fns = {"fwd": lambda: ops.conv2d_fwd(x, w, y, k, s, p, groups=g, stats=(st[0], st[1])),
+               "fused": lambda: ops.conv2d_fwd(x, w, y, k, s, p, groups=g, bias=bias, silu=True),      # the inference conv (BN folded)
                "dgrad": lambda: ops.conv2d_dgrad(dy, wt, dx, (B, OH, OW, N), k, s, p, groups=g),
                "wgrad": lambda: ops.conv2d_wgrad(x, dy, dw, k, s, p, groups=g)}
         row = f"{H:3d}x{W:<3d} {C:4d}->{N:<4d} k{k} s{s} g{g:<3d} x{cnt}"
