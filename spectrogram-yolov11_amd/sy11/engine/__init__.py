@@ -321,6 +321,10 @@ class EngineFn(torch.autograd.Function):
 # GradStore id -> callable(GradStore): set by the data-parallel wrapper to all-reduce the flat gradient buffer
 module_post_backward = {}
 
+# Only the capturing thread's calls can invalidate a capture: under the default "global" mode a helper thread of the process
+# (RCCL's watchdog polling its events while another rank is still reducing) would abort the capture of the training graphs.
+_CAPTURE_MODE = "thread_local"
+
 
 class _Graphed:
     """One captured (forward graph, backward graph) pair for a fixed input signature of a module.
@@ -345,7 +349,7 @@ class _Graphed:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             self.g_fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fwd, stream=side):
+            with torch.cuda.graph(self.g_fwd, stream=side, capture_error_mode=_CAPTURE_MODE):
                 ec = Ctx(True, True, dtype, dev, store, module.__dict__.get("_sy11_pool_hint", 0))
                 ec.capturing = True
                 ec.attach_flat(module)
@@ -358,7 +362,7 @@ class _Graphed:
             self.static_out = [from_act(a) for a in self.outs]
             self.static_gout = [torch.zeros_like(a.data) for a in self.outs]      # NHWC, activation dtype
             self.g_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), stream=side):
+            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), stream=side, capture_error_mode=_CAPTURE_MODE):
                 for a, g in zip(self.outs, self.static_gout):
                     if a.data.dim() == 4:
                         a.set_grad(g)
@@ -382,7 +386,7 @@ class _GraphedFwd:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             self.g_fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fwd, stream=side):
+            with torch.cuda.graph(self.g_fwd, stream=side, capture_error_mode=_CAPTURE_MODE):
                 ec = Ctx(module.training, False, dtype, dev, None, module.__dict__.get("_sy11_pool_hint", 0))
                 ec.capturing = True
                 ec.attach_flat(module)
