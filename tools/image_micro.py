@@ -94,6 +94,22 @@ def main():
         pr.disable()
         buf = io.StringIO(); pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(14)
         print("\n".join(l[:150] for l in buf.getvalue().splitlines() if l.strip())[:3000])
+        if "--train" in sys.argv:
+            # end to end: files -> loader -> fused augmentation into the graph's static input -> yolo11s train step (f16)
+            from sy11.engine.trainer import DetectionTrainer
+            from sy11.nn.tasks import DetectionModel
+            model = DetectionModel("yolo11s.yaml", nc=2, verbose=False)
+            tr = DetectionTrainer(model, batch_size=B, device="cuda", overrides={"amp": True}, graphs=True)
+            dl2 = build_dataloader(ds, B, workers=8, out=tr.batch_buffer(S), dtype=torch.float32)
+            it2 = iter(dl2)
+            for _ in range(5):                                   # eager warm-up + tuner + graph capture
+                tr.train_step(next(it2))
+            torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
+            for epoch in range(3):
+                for batch in dl2:
+                    tr.train_step(batch); nb += 1
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            print(f"train from files yolo11s f16, {nb} steps of {B}: {nb * B / dt:8.0f} img/s ({dt / nb * 1e3:.1f} ms/step; synthetic-data step 23.7-24.6 ms)")
         # CPU oracle on a few samples: the same chain in numpy
         from oracle import image_ref as IR
         t0 = time.perf_counter(); k = 4
