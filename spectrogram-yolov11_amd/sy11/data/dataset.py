@@ -40,12 +40,32 @@ def img2label_paths(img_paths):
     return [sb.join(x.rsplit(sa, 1)).rsplit(".", 1)[0] + ".txt" for x in img_paths]
 
 
+_NPY_META = {}          # path -> (shape, data offset) of plain uint8 C-order .npy files: later reads are one np.fromfile call
+
+
+def _load_npy(path):
+    """np.load for the common case (uint8, C order, no pickle) without re-parsing the header on every epoch: the header costs
+    more interpreter time than the 1.2 MB read itself, and the read (np.fromfile) releases the GIL."""
+    key = str(path)
+    meta = _NPY_META.get(key)
+    if meta is None:
+        with open(path, "rb") as f:
+            version = np.lib.format.read_magic(f)
+            shape, fortran, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
+            meta = (shape, f.tell()) if (dtype == np.uint8 and not fortran) else False
+        _NPY_META[key] = meta
+    if meta is False:
+        return np.load(path)
+    shape, offset = meta
+    return np.fromfile(path, dtype=np.uint8, count=int(np.prod(shape)), offset=offset).reshape(shape)
+
+
 def read_image(path):
     """Decode to (h, w, 3) uint8 BGR like cv2.imread (base.py:153-165): a sibling / direct .npy wins, else PIL."""
     p = Path(path)
     npy = p if p.suffix == ".npy" else p.with_suffix(".npy")
     if npy.exists():
-        im = np.load(npy)
+        im = _load_npy(npy)
     else:
         from PIL import Image
         with Image.open(p) as f:
@@ -187,9 +207,8 @@ class YOLODataset:
         im = self.ims[i]
         if im is None:
             fut = self._decoding.pop(i, None)
-            raw = fut.result() if fut is not None else read_image(self.im_files[i])
-            h0, w0 = raw.shape[:2]
-            src = torch.from_numpy(raw).to(self.device, non_blocking=True) if self.device.type == "cuda" else torch.from_numpy(raw)
+            src = fut.result() if fut is not None else self._decode_upload(i)
+            h0, w0 = src.shape[:2]
             if rect_mode:
                 r = self.imgsz / max(h0, w0)
                 size = (min(math.ceil(h0 * r), self.imgsz), min(math.ceil(w0 * r), self.imgsz)) if r != 1 else (h0, w0)
@@ -208,6 +227,12 @@ class YOLODataset:
                     self.ims[j], self.im_hw0[j], self.im_hw[j] = None, None, None
             return im, (h0, w0), tuple(im.shape[:2])
         return self.ims[i], self.im_hw0[i], self.im_hw[i]
+
+    def _decode_upload(self, i):
+        """File -> uint8 HWC tensor on the device.  Also what the loader's background threads run for the coming batch: file
+        reads and the pageable host-to-device copy both release the GIL, so they overlap the main thread's recipe code."""
+        raw = torch.from_numpy(read_image(self.im_files[i]))
+        return raw.to(self.device) if self.device.type == "cuda" else raw
 
     def get_image_and_label(self, index):
         """base.py:290-301 + dataset.py:204-229 (update_labels_info)."""
@@ -339,7 +364,7 @@ class InfiniteDataLoader:
             ds = self.dataset
             for i in indices:
                 if ds.ims[i] is None and i not in ds._decoding:
-                    ds._decoding[i] = self.pool.submit(read_image, ds.im_files[i])
+                    ds._decoding[i] = self.pool.submit(ds._decode_upload, i)
 
     def _forever(self):
         while True:
