@@ -69,7 +69,7 @@ def main():
             (root / "labels" / f"s{i:04d}.txt").write_text("\n".join(" ".join(f"{v:.6f}" for v in r) for r in rows))
         ds = YOLODataset(str(root / "images"), imgsz=S, augment=True, batch_size=B, data={"nc": 2})
         static = torch.empty((B, 3, S, S), device="cuda")
-        dl = build_dataloader(ds, B, workers=8, out=static, dtype=torch.float32)
+        dl = build_dataloader(ds, B, workers=int(__import__("os").environ.get("SY11_LOADER_THREADS", "8")), out=static, dtype=torch.float32)
         it = iter(dl)
         next(it)
         torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
