@@ -2,6 +2,7 @@
 // 3-channel stem.  Both are HBM/L2-bound (depthwise: 4.5 FLOP/B; stem: K = 27), so no MFMA: a thread owns a fixed
 // 16-byte channel vector, keeps its filter taps in registers and walks pixels; neighbouring taps are L1/L2 hits.
 #include "common.h"
+#include <type_traits>
 #include "bn_tail.h"
 
 template <typename T, int VEC>
@@ -244,6 +245,90 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int d
       const int ch = e / Tn, t = e - ch * Tn;
       atomicAdd(base + e, red[ch / VEC][t * VEC + (ch % VEC)]);
     }
+  }
+}
+
+// f16, 3x3: the same sum with the per-pixel work cut to what it needs.  The generic kernel above spends ~2200 issue cycles
+// per pixel and wave on 43 integer multiplies (nine independent tap addresses), 80 f16->f32 conversions and 36 mask
+// multiplies; here the three row bases and three column offsets are formed once (6 multiplies), the pixel coordinates
+// advance without divisions, out-of-image taps become zero VECTORS (16-byte selects on the loaded halves) and the
+// products are written as (float)h * (float)h + f32 so the compiler emits v_fma_mix_f32 — no conversions at all.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void dwconv_wgrad3x3_f16_kernel(const DwArgs a, int dy_ld, float* dw) {
+  constexpr int VEC = 8, MAXT = 9;
+  __shared__ float red[256][MAXT * VEC + 1];
+  const int cw = a.cpv < 256 ? a.cpv : 256;
+  const int cl = threadIdx.x % cw, cv = blockIdx.y * 256 + cl, rsub = threadIdx.x / cw;
+  const bool active = cv < a.cpv && rsub < a.rows_pb;
+  const int c = cv * VEC;
+  float acc[MAXT][VEC];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+  if (active) {
+    const int M = a.B * a.OH * a.OW;
+    const int m0 = blockIdx.x * (int)a.rows_per_block;
+    const int m1 = m0 + (int)a.rows_per_block < M ? m0 + (int)a.rows_per_block : M;
+    int m = m0 + rsub;
+    int q = m / a.OW, ox = m - q * a.OW;
+    int b = q / a.OH, oy = q - b * a.OH;
+    const _Float16* xb = (const _Float16*)a.x + c;
+    const _Float16* dyb = (const _Float16*)a.y + c;                   // a.y = dy here
+    const long row_elems = (long)a.IW * a.x_ld;
+    const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (; m < m1; m += a.rows_pb) {
+      const h16x8 g = *(const h16x8*)(dyb + (long)m * dy_ld);
+      const _Float16* rowp[3];
+      bool rok[3], cok[3];
+      int coff[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int iy = oy * a.SH - a.PH + r * a.DH;
+        rok[r] = (unsigned)iy < (unsigned)a.IH;
+        const int cy = min(max(iy, 0), a.IH - 1);
+        rowp[r] = xb + (long)(b * a.IH + cy) * row_elems;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        const int ix = ox * a.SW - a.PW + s2 * a.DW;
+        cok[s2] = (unsigned)ix < (unsigned)a.IW;
+        coff[s2] = min(max(ix, 0), a.IW - 1) * a.x_ld;
+      }
+      h16x8 tv[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) tv[t] = *(const h16x8*)(rowp[t / 3] + coff[t % 3]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const h16x8 v = (rok[t / 3] && cok[t % 3]) ? tv[t] : zero;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[t][i] += (float)g[i] * (float)v[i];
+      }
+      // advance rows_pb pixels without dividing (rows_pb <= 256 may span several short rows)
+      ox += a.rows_pb;
+      while (ox >= a.OW) { ox -= a.OW; ++oy; }
+      while (oy >= a.OH) { oy -= a.OH; ++b; }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[threadIdx.x][t * VEC + i] = acc[t][i];
+  __syncthreads();
+  int half = 1;
+  while (half < a.rows_pb) half <<= 1;
+  for (half >>= 1; half >= 1; half >>= 1) {
+    if (rsub < half && rsub + half < a.rows_pb) {
+#pragma unroll
+      for (int e = 0; e < MAXT * VEC; ++e) red[threadIdx.x][e] += red[threadIdx.x + half * cw][e];
+    }
+    __syncthreads();
+  }
+  const int nch = min(cw, a.cpv - (int)blockIdx.y * 256) * VEC;
+  float* base = dw + (long)blockIdx.y * 256 * VEC * 9;
+  for (int e = threadIdx.x; e < nch * 9; e += 256) {
+    const int ch = e / 9, t = e - ch * 9;
+    atomicAdd(base + e, red[ch / VEC][t * VEC + (ch % VEC)]);
   }
 }
 
@@ -520,7 +605,8 @@ extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, cons
   }
   SY11_DISPATCH_DTYPE(d->dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
-    if (vec) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, VE, 9>), grid, dim3(256), 0, st, a, dy_ld, dw);
+    if (vec && std::is_same<T, _Float16>::value && d->KH == 3 && d->KW == 3) hipLaunchKernelGGL(dwconv_wgrad3x3_f16_kernel, grid, dim3(256), 0, st, a, dy_ld, dw);
+    else if (vec) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, VE, 9>), grid, dim3(256), 0, st, a, dy_ld, dw);
     else hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 1, 9>), grid, dim3(256), 0, st, a, dy_ld, dw);
   });
   SY11_LAUNCH_CHECK("dwconv_wgrad");
