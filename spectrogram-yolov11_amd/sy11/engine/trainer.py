@@ -127,6 +127,56 @@ class DetectionTrainer:
                 opt.state[t]["momentum_buffer"] = torch.zeros_like(t)
         return opt
 
+    # ---- resume (engine/trainer.py:728-756)
+    def resume_training(self, ckpt):
+        """Take optimizer state, EMA and epoch counter from a checkpoint dict (this build's or the reference's).  The model
+        weights are the caller's business, as in the reference (the model is built from the checkpoint first).  Returns the
+        epoch to continue with."""
+        start_epoch = ckpt.get("epoch", -1) + 1
+        if ckpt.get("optimizer") is not None:
+            self._load_optimizer_state(ckpt["optimizer"])
+        if self.ema and ckpt.get("ema") is not None:
+            self.ema.ema.load_state_dict(ckpt["ema"].float().state_dict())      # in place: the flat EMA buffers keep their views
+            self.ema.updates = ckpt.get("updates", 0)
+        self.epoch = start_epoch
+        return start_epoch
+
+    def _load_optimizer_state(self, osd):
+        """An optimizer state_dict in this trainer's flat layout (one tensor per group) loads as it is; the reference's
+        per-parameter layout — groups [biases, decayed weights, norm weights], parameters in named_modules order — is
+        scattered into the flat momentum / Adam buffers slice by slice."""
+        groups = osd["param_groups"]
+        flat_layout = all(len(g["params"]) == 1 for g in groups)
+        if self.flat is None or flat_layout:
+            self.optimizer.load_state_dict(osd)
+            return
+        from .flat import _view_like, param_groups
+        mine = param_groups(self.model)                                # (decay, norm, bias) lists, reference iteration order
+        lists = (mine[2], mine[0], mine[1])                            # the reference's group order: bias, decay, norm
+        if len(groups) != 3 or any(len(g["params"]) != len(l) for g, l in zip(groups, lists)):
+            raise ValueError("optimizer state does not match this model's parameter groups "
+                             f"({[len(g['params']) for g in groups]} vs {[len(l) for l in lists]})")
+        starts = {0: self.flat.group_slices[2][0], 1: self.flat.group_slices[0][0], 2: self.flat.group_slices[1][0]}
+        for k, (g, plist) in enumerate(zip(groups, lists)):
+            og = self.optimizer.param_groups[k]
+            flat_t = og["params"][0]
+            st = self.optimizer.state[flat_t]
+            for key, val in g.items():
+                if key != "params" and key in og and key not in ("fused", "foreach", "capturable", "differentiable", "maximize"):
+                    og[key] = val
+            for idx, p in zip(g["params"], plist):
+                ps = osd["state"].get(idx)
+                if not ps:
+                    continue
+                off = self.flat.offsets[id(p)] - starts[k]
+                for name, val in ps.items():
+                    if torch.is_tensor(val) and val.dim() > 0 and val.numel() == p.numel():
+                        if name not in st:
+                            st[name] = torch.zeros_like(flat_t)
+                        _view_like(st[name][off:off + p.numel()], p).copy_(val.to(flat_t.device, torch.float32))
+                    elif name == "step":
+                        st["step"] = torch.as_tensor(float(val), dtype=torch.float32, device=flat_t.device if self.optimizer.defaults.get("fused") else "cpu")
+
     # ---- learning-rate schedule and warm-up (engine/trainer.py:209-215, :330, :364-377, :430-433)
     def set_schedule(self, batches_per_epoch, epochs, lrf=0.01, cos_lr=False):
         """Arm the per-iteration warm-up and the per-epoch LambdaLR of the reference for a run of ``epochs`` x ``batches_per_epoch``."""

@@ -87,3 +87,56 @@ def test_train_val_predict_resume_flow(tmp_path):
     tr2 = DetectionTrainer(model2, batch_size=B, device=DEV, overrides={"amp": True, "nbs": B, "imgsz": S}, graphs=True)
     more = [float(tr2.train_step(batch)[0]) for batch in dl]
     assert all(np.isfinite(more)) and np.mean(more) < 3 * np.mean(losses[-len(dl):]) + 1e-6      # continues from a trained state, not from scratch
+
+
+def _tiny_batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"img": torch.rand(4, 3, 64, 64, generator=g).to(DEV), "batch_idx": torch.tensor([0., 1., 2., 3.]).to(DEV),
+            "cls": torch.tensor([[1.], [0.], [1.], [0.]]).to(DEV), "bboxes": (0.3 + 0.3 * torch.rand(4, 4, generator=g)).to(DEV)}
+
+
+@pytest.mark.parametrize("opt", ["SGD", "AdamW"])
+def test_resume_from_flat_and_from_reference_layout_optimizer_state(opt):
+    """resume_training (engine/trainer.py:728-756): optimizer state + EMA + epoch.  (a) a checkpoint of this build (flat
+    groups, fp16-converted state as the reference stores it) resumes into the same buffers; (b) a per-parameter state_dict
+    in the reference's layout lands in the same flat momentum buffers as training in the flat layout produced."""
+    from oracle import yolo11_ref as R
+    from sy11.engine.checkpoint import load_checkpoint, save_checkpoint
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+    sd = R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=2)), seed=4)
+
+    def make(flat):
+        m = DetectionModel("yolo11n.yaml", nc=2, verbose=False)
+        m.load_state_dict(sd)
+        return DetectionTrainer(m, batch_size=4, device=DEV, overrides={"amp": False, "nbs": 4, "optimizer": opt, "lr0": 1e-3}, graphs=False, flat=flat)
+
+    a, b = make(True), make(False)                       # flat groups vs the reference's per-parameter optimizer
+    for i in range(3):
+        a.train_step(_tiny_batch(i))
+        b.train_step(_tiny_batch(i))
+    key = "momentum_buffer" if opt == "SGD" else "exp_avg"
+    flat_mom = [a.optimizer.state[g["params"][0]][key].clone() for g in a.optimizer.param_groups]
+    # (b) reference layout -> flat
+    c = make(True)
+    c.resume_training({"epoch": 4, "optimizer": b.optimizer.state_dict(), "ema": None})
+    assert c.epoch == 5
+    for g, want in zip(c.optimizer.param_groups, flat_mom):
+        got = c.optimizer.state[g["params"][0]][key]
+        # two independent 3-step trainings (f32 atomics reorder; AdamW amplifies it): same layout <=> the vectors line up
+        cos = float(torch.dot(got, want) / (got.norm() * want.norm() + 1e-30))
+        assert got.shape == want.shape and cos > (0.999 if opt == "SGD" else 0.97), cos
+    # (a) this build's checkpoint (state stored in fp16) -> a fresh flat trainer
+    buf = io.BytesIO()
+    save_checkpoint(buf, trainer=a, epoch=2)
+    ck = load_checkpoint(io.BytesIO(buf.getvalue()))
+    d = make(True)
+    assert d.resume_training(ck) == 3 and d.ema.updates == a.ema.updates
+    for g, want in zip(d.optimizer.param_groups, flat_mom):
+        got = d.optimizer.state[g["params"][0]][key]
+        assert torch.allclose(got, want.half().float(), rtol=1e-3, atol=1e-6)
+    for (k1, p), (_, q) in zip(a.ema.ema.state_dict().items(), d.ema.ema.state_dict().items()):
+        if p.dtype.is_floating_point:
+            assert torch.allclose(p.half().float(), q, rtol=1e-3, atol=1e-4), k1
+    loss = float(d.train_step(_tiny_batch(9))[0])          # and it keeps training
+    assert np.isfinite(loss)
