@@ -127,10 +127,18 @@ def _optimizer_state_fp16(sd):
 def checkpoint_dict(ema_model: nn.Module, updates=0, optimizer=None, epoch=0, best_fitness=None, train_args=None, train_metrics=None,
                     train_results=None):
     """The dictionary trainer.save_model writes (same keys); ``ema`` = detached f16 copy of the EMA model."""
-    ema = deepcopy(ema_model)
-    for m in ema.modules():                                  # engine caches (graphs, flat state, grad store) never travel
-        for k in [k for k in m.__dict__ if k.startswith("_sy11_")]:
-            del m.__dict__[k]
+    # engine caches (captured graphs, flat state, grad store) never travel — and a CUDAGraph cannot be deep-copied: set them
+    # aside for the copy
+    stash = []
+    for m in ema_model.modules():
+        held = {k: m.__dict__.pop(k) for k in [k for k in m.__dict__ if k.startswith("_sy11_")]}
+        if held:
+            stash.append((m, held))
+    try:
+        ema = deepcopy(ema_model)
+    finally:
+        for m, held in stash:
+            m.__dict__.update(held)
     for p in ema.parameters():                               # parameters may be views of a flat buffer: give them own storage
         p.data = p.data.clone()
     for b in ema.buffers():

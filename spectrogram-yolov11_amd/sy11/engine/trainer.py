@@ -127,6 +127,58 @@ class DetectionTrainer:
                 opt.state[t]["momentum_buffer"] = torch.zeros_like(t)
         return opt
 
+    # ---- the epoch loop (engine/trainer.py:318-474 `_do_train`, without callbacks / plots / logging)
+    def fit(self, train_loader, epochs, val_batches=None, save_dir=None, close_mosaic=10, start_epoch=0, lrf=0.01, cos_lr=False,
+            patience=100):
+        """Epochs of: [close mosaic for the last `close_mosaic` epochs] -> iterations (warm-up, accumulate, step, EMA) ->
+        scheduler step -> validate the EMA model -> fitness -> save last / best.  ``val_batches``: a callable returning an
+        iterable of validation batches (or None: no validation).  Returns the per-epoch records.  Every rank runs the same
+        number of iterations; validation and checkpoints happen on rank 0 only (RANK env), as in the reference."""
+        import os
+        from pathlib import Path
+        from .checkpoint import save_checkpoint
+        from .validator import DetectionValidator
+        rank0 = int(os.environ.get("RANK", "-1")) in (-1, 0)
+        self.set_schedule(len(train_loader), epochs, lrf=lrf, cos_lr=cos_lr)
+        self.epoch = start_epoch
+        if start_epoch:
+            for g in self.optimizer.param_groups:
+                g["lr"] = g["initial_lr"] * self.lf(start_epoch)
+            self.ni = start_epoch * self.nb
+            self.last_opt_step = self.ni - 1
+        best, stale, history = -1.0, 0, []
+        save_dir = Path(save_dir) if save_dir else None
+        if save_dir and rank0:
+            save_dir.mkdir(parents=True, exist_ok=True)
+        for epoch in range(start_epoch, epochs):
+            if epoch == epochs - close_mosaic and hasattr(train_loader.dataset, "close_mosaic"):
+                train_loader.dataset.close_mosaic(train_loader.dataset.hyp)       # trainer.py:341-343
+            if hasattr(train_loader, "set_epoch"):
+                train_loader.set_epoch(epoch)
+            tloss = None
+            for i, batch in enumerate(train_loader):
+                _, items = self.train_step(batch)
+                tloss = items if tloss is None else (tloss * i + items) / (i + 1)  # trainer.py:385-387 running mean of the 3 loss items
+            self.end_epoch()
+            rec = {"epoch": epoch, "train_loss": [float(v) for v in tloss] if tloss is not None else None, "metrics": None, "fitness": None}
+            if rank0 and val_batches is not None:
+                metrics = DetectionValidator(self.ema.ema if self.ema else self.model, device=self.device,
+                                             half=self.amp)(self.ema.ema if self.ema else self.model, val_batches())
+                rec["metrics"] = metrics
+                rec["fitness"] = float(metrics.get("fitness", 0.1 * metrics.get("metrics/mAP50(B)", 0.0) + 0.9 * metrics.get("metrics/mAP50-95(B)", 0.0)))
+            if rank0 and save_dir:
+                save_checkpoint(save_dir / "last.pt", trainer=self, epoch=epoch, best_fitness=max(best, rec["fitness"] or -1.0),
+                                train_metrics=rec["metrics"])
+                if rec["fitness"] is None or rec["fitness"] >= best:
+                    save_checkpoint(save_dir / "best.pt", trainer=self, epoch=epoch, best_fitness=rec["fitness"], train_metrics=rec["metrics"])
+            if rec["fitness"] is not None:
+                stale = 0 if rec["fitness"] >= best else stale + 1               # EarlyStopping (utils/torch_utils.py:713-757)
+                best = max(best, rec["fitness"])
+            history.append(rec)
+            if patience and stale >= patience:
+                break
+        return history
+
     # ---- resume (engine/trainer.py:728-756)
     def resume_training(self, ckpt):
         """Take optimizer state, EMA and epoch counter from a checkpoint dict (this build's or the reference's).  The model

