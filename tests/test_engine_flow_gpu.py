@@ -171,3 +171,27 @@ def test_fit_loop_validates_saves_and_closes_mosaic(tmp_path):
     with torch.no_grad():
         y, _ = model(torch.rand(1, 3, S, S, device=DEV))
     assert tuple(y.shape) == (1, 6, 3 * (S // 8) ** 2 // 1 - 0 if False else y.shape[2]) and torch.isfinite(y).all()
+
+
+def test_yolo_front_door_train_val_predict(tmp_path):
+    """`YOLO(cfg).train(data=yaml) / .val() / .predict()` — the reference's entry points (engine/model.py) on a data YAML."""
+    from sy11 import YOLO
+    S = 96
+    _dataset(tmp_path / "ds" / "train", 12, S, 5)
+    _dataset(tmp_path / "ds" / "val", 6, S, 6)
+    (tmp_path / "ds" / "data.yaml").write_text("path: .\ntrain: train/images\nval: val/images\nnames:\n  0: bright\n  1: dark\n")
+    y = YOLO("yolo11n.yaml", device=DEV)
+    hist = y.train(data=str(tmp_path / "ds" / "data.yaml"), epochs=2, batch=6, imgsz=S, workers=0, save_dir=tmp_path / "run", close_mosaic=1,
+                   warmup_epochs=0.5, fliplr=0.0)
+    assert len(hist) == 2 and y.model.names == {0: "bright", 1: "dark"} and y.ckpt is not None          # continues with best.pt
+    m = y.val(data=str(tmp_path / "ds" / "data.yaml"), batch=3, imgsz=S)
+    assert "metrics/mAP50(B)" in m or "fitness" in m
+    img = np.load(sorted((tmp_path / "ds" / "val" / "images").glob("*.npy"))[0])
+    res = y.predict(img, conf=0.001, imgsz=S)
+    assert len(res) == 1 and res[0].orig_shape == img.shape[:2]
+    res2 = y([str(p) for p in sorted((tmp_path / "ds" / "val" / "images").glob("*.npy"))[:2]], conf=0.001, imgsz=S)
+    assert len(res2) == 2 and res2[0].path.endswith(".npy")
+    with pytest.raises(SyntaxError):
+        y.train(data={"train": "x"}, epochs=1)
+    with pytest.raises(SyntaxError):
+        y.train(data=str(tmp_path / "ds" / "data.yaml"), epochs=1, not_an_argument=1)
