@@ -100,3 +100,18 @@ def test_multi_scale_oracle_shapes():
     y = IR.preprocess_batch_multi_scale(x, 128)
     assert tuple(y.shape) == (2, 3, 96, 128) and y.dtype == torch.float32
     assert tuple(IR.preprocess_batch_multi_scale(x, 96).shape) == (2, 3, 64, 96)
+
+
+def test_bus_jpg_letterbox_matches_reference_flow():
+    """BASELINE configs[0] plumbing: the reference's LetterBox(auto) on bus.jpg (1080 x 810 -> 640 x 480); the oracle reproduces
+    the recorded letterboxed image byte for byte (sha256) and the preprocessed tensor's samples."""
+    import hashlib
+    from PIL import Image
+    from tests._golden import GOLD, check
+    gold = load("bus.npz")
+    im0 = np.ascontiguousarray(np.asarray(Image.open(GOLD / "bus.jpg").convert("RGB"))[..., ::-1])
+    assert tuple(gold["orig_shape"]) == im0.shape == (1080, 810, 3)
+    lb, ratio, pad = IR.letterbox(im0, (640, 640), auto=True, stride=32)
+    assert tuple(gold["letterbox_shape"]) == lb.shape == (640, 480, 3) and pad == (0, 0)
+    assert hashlib.sha256(np.ascontiguousarray(lb).tobytes()).digest() == gold["letterbox_sha256"].tobytes()
+    check(gold, "im", IR.predictor_preprocess([im0], (640, 640), stride=32), rtol=1e-9, atol=0)

@@ -90,3 +90,27 @@ def test_forward_graph_replay_is_bit_identical_to_eager():
     assert len(cfg["entries"]) == 2 and all(torch.equal(outs[0], o) for o in outs[1:])
     res = pred(imgs[0])
     assert len(res) == 2
+
+
+def test_bus_jpg_predict_matches_reference_cpu_path():
+    """BASELINE configs[0]: YOLOv11-n predict on bus.jpg.  Golden = the REFERENCE's LetterBox + preprocess + fused eval
+    DetectionModel on the CPU (oracle/gen_golden_bus.py).  Preprocessed tensor bit-exact, decoded predictions within 1e-3 of
+    their scale, kept boxes / class ids after NMS identical to the oracle's NMS on the same predictions."""
+    from PIL import Image
+    from sy11.engine.predictor import DetectionPredictor
+    from tests._golden import GOLD, check, load
+    gold = load("bus.npz")
+    im0 = np.ascontiguousarray(np.asarray(Image.open(GOLD / "bus.jpg").convert("RGB"))[..., ::-1])      # cv2.imread order
+    m, _ = build()
+    pred = DetectionPredictor(m, device=DEV, conf=0.25, iou=0.7, imgsz=640)
+    im = pred.preprocess([im0])
+    assert tuple(im.shape) == (1, 3, 640, 480)
+    check(gold, "im", im, rtol=1e-9, atol=0)       # samples exact; the f64 moments only see summation order
+    y, _ = pred.inference(im)
+    check(gold, "pred", y, rtol=1e-3, atol=1e-3)
+    ref_out, _ = nms_ref.non_max_suppression(y.cpu().clone(), 0.25, 0.7, multi_label=False, max_det=300)
+    res = pred.postprocess(y.clone(), im, orig_imgs=[im0])
+    got = res[0].boxes.data.cpu()
+    assert got.shape[0] == ref_out[0].shape[0] and got.shape[0] > 0
+    assert torch.equal(got[:, 5], ref_out[0][:, 5]) and torch.equal(got[:, 4], ref_out[0][:, 4])          # class ids and scores of the kept rows
+    assert res[0].orig_shape == (1080, 810)
