@@ -183,11 +183,21 @@ def main():
                     "conv_roofline_frac": round(a.batch / fdt * FWD_GFLOP_PER_IMG / 1e3 / PEAK_TFLOPS[a.dtype], 4)}
 
     roof = None
+    if world > 1 and not a.no_roofline:
+        step()                                                  # every rank takes the extra step: its gradient all-reduce must be matched
     if rank == 0 and not a.no_roofline:
         # one instrumented step: every C-ABI launch bracketed by events on the launch stream
         tr.model.__dict__.pop("_sy11_graph_cfg", None)          # per-launch events need individually launched kernels
         _lib.PROFILE = []
-        step()
+        if world == 1:
+            step()
+        else:                                                   # the collective already happened above: instrument forward+backward only
+            store = tr.model.__dict__.get("_sy11_grads")
+            from sy11.engine import module_post_backward
+            hook = module_post_backward.pop(id(store), None) if store is not None else None
+            step()
+            if hook is not None:
+                module_post_backward[id(store)] = hook
         torch.cuda.synchronize()
         prof, _lib.PROFILE = _lib.PROFILE, None
         fam = {}
