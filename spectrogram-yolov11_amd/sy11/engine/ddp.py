@@ -55,7 +55,25 @@ def attach(model: torch.nn.Module, group=None):
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
-    """Rank-0 weights and buffers to everybody (what DDP's constructor does)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src, group=group)
+    """Rank-0 weights and buffers to everybody (what DDP's constructor does).  With a flat layout (engine/flat.py) that is two
+    broadcasts of the flat buffers plus the few tensors living outside them; otherwise one per tensor (through a contiguous
+    staging copy when a backend cannot take the tensor's strides)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    flat = model.__dict__.get("_sy11_flat")
+    covered = []
+    if flat is not None:
+        for buf in (flat.flat, flat.flat_buf):
+            if buf.numel():
+                dist.broadcast(buf, src, group=group)
+                covered.append((buf.data_ptr(), buf.data_ptr() + buf.numel() * buf.element_size()))
+    for t in list(model.parameters()) + list(model.buffers()):
+        d = t.data
+        if any(lo <= d.data_ptr() < hi for lo, hi in covered):
+            continue
+        if d.is_contiguous():
+            dist.broadcast(d, src, group=group)
+        else:
+            c = d.contiguous()
+            dist.broadcast(c, src, group=group)
+            d.copy_(c)

@@ -49,13 +49,13 @@ class DetectionTrainer:
             from . import GradStore
             from .flat import FlatEMA, FlatState
             self.flat = FlatState(self.model)
-            if world_size > 1:                               # DDP's constructor: rank-0 weights and buffers to everybody,
-                ddp.broadcast_parameters(self.model)         # before the EMA takes its copy
             store = GradStore(self.model, order=self.flat.order)
             store.external_zero = True
             store.begin_backward(self.device)
             self.model.__dict__["_sy11_grads"] = store
             self.model.__dict__["_sy11_flat"] = self.flat
+            if world_size > 1:                               # DDP's constructor: rank-0 weights and buffers to everybody (two
+                ddp.broadcast_parameters(self.model)         # broadcasts of the flat buffers), before the EMA takes its copy
             self.grad_store = store
             self.flat_params = [t.requires_grad_(True) for t in self.flat.group_tensors(self.flat.flat)]
             self.flat_grads = self.flat.group_tensors(store.flat)

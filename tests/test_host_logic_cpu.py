@@ -149,6 +149,20 @@ DDP_SCRIPT = textwrap.dedent("""
         g_.copy_(r)
         dist.broadcast(g_, 0)
         assert torch.equal(g_, r)                          # parameters identical on both ranks after the broadcast
+    # flat layout: two broadcasts of the flat buffers + the tensors outside them (integer BN counters)
+    from sy11.engine.flat import FlatState
+    torch.manual_seed(0)
+    m2 = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, bias=False), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 18, 1))
+    fs = FlatState(m2)
+    m2.__dict__["_sy11_flat"] = fs
+    if rank == 1:
+        fs.flat.add_(3.0); fs.flat_buf.add_(2.0); m2[1].num_batches_tracked.add_(7)
+    ddp.broadcast_parameters(m2)
+    mine = torch.cat([fs.flat, fs.flat_buf, m2[1].num_batches_tracked.float().view(1)])
+    theirs = mine.clone()
+    dist.broadcast(theirs, 0)
+    assert torch.equal(mine, theirs) and int(m2[1].num_batches_tracked) == 0
+    assert m2[0].weight.data_ptr() >= fs.flat.data_ptr() and not m2[0].weight.is_contiguous()      # a permuted view of the flat buffer
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
