@@ -170,7 +170,8 @@ def test_fit_loop_validates_saves_and_closes_mosaic(tmp_path):
     assert ck["epoch"] in (0, 1, 2) and ck["train_metrics"] is not None
     with torch.no_grad():
         y, _ = model(torch.rand(1, 3, S, S, device=DEV))
-    assert tuple(y.shape) == (1, 6, 3 * (S // 8) ** 2 // 1 - 0 if False else y.shape[2]) and torch.isfinite(y).all()
+    n_anchors = (S // 8) ** 2 + (S // 16) ** 2 + (S // 32) ** 2
+    assert tuple(y.shape) == (1, 4 + 2, n_anchors) and torch.isfinite(y).all()
 
 
 def test_yolo_front_door_train_val_predict(tmp_path):

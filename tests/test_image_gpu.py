@@ -77,7 +77,7 @@ def test_predictor_pre_transform_matches_reference_flow(same):
     pred.model = type("M", (), {"stride": torch.tensor([8.0, 16.0, 32.0]), "_sy11_dtype": torch.float32})()
     got = pred.preprocess(ims)
     want = IR.predictor_preprocess(ims, (64, 64), stride=32)
-    assert got.dtype == torch.float32 and tuple(got.shape) == tuple(want.shape) == ((3, 3, 64, 64) if not same else (3, 3, 64, 64))
+    assert got.dtype == torch.float32 and tuple(got.shape) == tuple(want.shape) == (3, 3, 64, 64)
     assert torch.equal(got.cpu(), want)
     half = pred.pre_transform(ims, out_dtype=torch.float16)
     assert torch.equal(half.cpu(), IR.predictor_preprocess(ims, (64, 64), stride=32).half())
