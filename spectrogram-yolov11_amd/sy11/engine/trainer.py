@@ -69,7 +69,8 @@ class DetectionTrainer:
             self.ema = ModelEMA(self.model)
         if world_size > 1:
             ddp.attach(self.model)
-        if graphs:                                          # hipGraph replay of forward/backward after 2 eager steps
+        if graphs and not self.args.multi_scale:            # hipGraph replay of forward/backward after 2 eager steps (multi_scale draws a new
+            # input size every step: one captured graph + activation pool per size would not pay, those runs stay eager)
             from . import enable_graphs
             enable_graphs(self.model)
         self.last_opt_step = -1
