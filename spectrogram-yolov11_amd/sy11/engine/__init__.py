@@ -324,6 +324,7 @@ module_post_backward = {}
 # Only the capturing thread's calls can invalidate a capture: under the default "global" mode a helper thread of the process
 # (RCCL's watchdog polling its events while another rank is still reducing) would abort the capture of the training graphs.
 _CAPTURE_MODE = "thread_local"
+_MAX_FWD_GRAPHS = 8
 
 
 class _Graphed:
@@ -484,7 +485,9 @@ def run_module(module, x):
         if entry is None:
             n = cfg["seen"].get(key, 0)
             cfg["seen"][key] = n + 1
-            if n >= cfg["warmup"]:
+            # at most a few forward-only graphs per module: rect validation feeds a different shape per batch, and every
+            # captured shape keeps its own activation pool alive
+            if n >= cfg["warmup"] and sum(1 for k in cfg["entries"] if len(k) == 4) < _MAX_FWD_GRAPHS:
                 entry = cfg["entries"][key] = _GraphedFwd(module, xs, is_list, dtype)
         if entry is not None:
             return entry(xs)
