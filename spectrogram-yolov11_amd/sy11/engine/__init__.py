@@ -448,16 +448,18 @@ def graph_static_input(module, shape, dtype=torch.float32):
 
 
 def graph_static_gout(module):
-    """Static output-gradient tensors (NHWC) of the module's captured backward graph, or None (single captured signature only)."""
+    """Static output-gradient tensors (NHWC) of the captured backward graph that belongs to the forward that just ran (a short
+    last batch has its own captured pair), or None when that forward was not a graph replay."""
     cfg = module.__dict__.get("_sy11_graph_cfg")
-    if not cfg or len(cfg["entries"]) != 1:
+    if not cfg:
         return None
-    return next(iter(cfg["entries"].values())).static_gout
+    last = cfg.get("last_train_entry")
+    return last.static_gout if last is not None else None
 
 
 def enable_graphs(module, warmup: int = 2):
     """Opt a module into hipGraph replay of its train-mode forward/backward (static shapes; see _Graphed)."""
-    module.__dict__["_sy11_graph_cfg"] = {"warmup": warmup, "seen": {}, "entries": {}}
+    module.__dict__["_sy11_graph_cfg"] = {"warmup": warmup, "seen": {}, "entries": {}, "last_train_entry": None}
     return module
 
 
@@ -474,6 +476,7 @@ def run_module(module, x):
             cfg["seen"][key] = n + 1
             if n >= cfg["warmup"]:
                 entry = cfg["entries"][key] = _Graphed(module, xs, is_list, dtype)
+        cfg["last_train_entry"] = entry                         # None while this signature is still running eagerly
         if entry is not None:
             params = [p for p in module.parameters()]
             return GraphFn.apply(entry, len(xs), *xs, *params)
