@@ -441,7 +441,10 @@ def graph_static_input(module, shape, dtype=torch.float32):
     cfg = module.__dict__.get("_sy11_graph_cfg")
     if not cfg:
         return None
-    for entry in cfg["entries"].values():
+    want_fwd = not (module.training and torch.is_grad_enabled())       # the same rule run_module uses to pick an entry kind
+    for key, entry in cfg["entries"].items():
+        if (len(key) == 4) != want_fwd:
+            continue
         if len(entry.static_in) == 1 and tuple(entry.static_in[0].shape) == tuple(shape) and entry.static_in[0].dtype == dtype:
             return entry.static_in[0]
     return None
