@@ -30,10 +30,10 @@ def _to_device_u8(img, device):
 
 
 class Compose:
-    """augment.py:82-195 — a list of transforms applied in order."""
+    """augment.py:82-195 — transforms applied in order; indexable with an int or a list of ints like the reference's."""
 
     def __init__(self, transforms):
-        self.transforms = transforms if isinstance(transforms, list) else [transforms]
+        self.transforms = list(transforms) if isinstance(transforms, (list, tuple)) else [transforms]
 
     def __call__(self, data):
         for t in self.transforms:
@@ -46,26 +46,30 @@ class Compose:
     def insert(self, index, transform):
         self.transforms.insert(index, transform)
 
+    @staticmethod
+    def _indices(index):
+        if isinstance(index, int):
+            return [index]
+        if isinstance(index, list) and all(isinstance(i, int) for i in index):
+            return index
+        raise TypeError(f"Compose indices must be an int or a list of ints, got {type(index).__name__}")
+
     def __getitem__(self, index):
-        assert isinstance(index, (int, list)), f"The indices should be either list or int type but got {type(index)}"
-        index = [index] if isinstance(index, int) else index
-        return Compose([self.transforms[i] for i in index])
+        return Compose([self.transforms[i] for i in self._indices(index)])
 
     def __setitem__(self, index, value):
-        assert isinstance(index, (int, list)), f"The indices should be either list or int type but got {type(index)}"
-        if isinstance(index, list):
-            assert isinstance(value, list), f"The indices should be the same type as values, but got {type(index)} and {type(value)}"
-        if isinstance(index, int):
-            index, value = [index], [value]
-        for i, v in zip(index, value):
-            assert i < len(self.transforms), f"list index {i} out of range {len(self.transforms)}."
-            self.transforms[i] = v
+        idx = self._indices(index)
+        vals = [value] if isinstance(index, int) else list(value)
+        if len(idx) != len(vals):
+            raise ValueError(f"{len(idx)} positions but {len(vals)} transforms")
+        for i, v in zip(idx, vals):
+            self.transforms[i] = v                     # IndexError for a position that does not exist
 
     def tolist(self):
         return self.transforms
 
     def __repr__(self):
-        return f"{self.__class__.__name__}({', '.join([f'{t}' for t in self.transforms])})"
+        return f"{type(self).__name__}({', '.join(map(str, self.transforms))})"
 
 
 class LetterBox:
