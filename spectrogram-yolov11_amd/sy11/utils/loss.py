@@ -153,6 +153,11 @@ class v8DetectionLoss:
             gt = self.preprocess(targets.to(self.device).float(), B, scale_tensor=scales[hw], batch_idx=batch["batch_idx"])
             loss, items = _FusedLossFn.apply(self, gt, *feats)
             return loss, items.detach()
+        if self.fused and self.reg_max == 16:
+            # never a silent detour: the hot-path criterion is the HIP one; the tensor-op formulation below is an explicit choice
+            from .. import _lib
+            raise _lib.Sy11Error("v8DetectionLoss: the fused criterion needs CUDA f32 head maps (got "
+                                 f"{[(str(f.device), str(f.dtype)) for f in feats]}); construct it with fused=False for the tensor-op formulation")
         loss = torch.zeros(3, device=self.device)
         # (B, no, H, W) with NHWC memory -> (B, H*W, no) without a copy; fall back to permute for NCHW-contiguous input
         flat = [xi.permute(0, 2, 3, 1).reshape(B, -1, self.no) for xi in feats]

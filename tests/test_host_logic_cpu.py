@@ -191,7 +191,9 @@ def test_loss_device_ops_match_oracle_on_cpu():
     det = SimpleNamespace(stride=torch.tensor([8., 16., 32.]), nc=nc, reg_max=16)
     model = SimpleNamespace(args=SimpleNamespace(box=7.5, cls=0.5, dfl=1.5), model=[det],
                             parameters=lambda: iter([torch.zeros(1)]))
-    crit = v8DetectionLoss(model)
+    crit = v8DetectionLoss(model, fused=False)           # the explicit tensor-op formulation (the default is the HIP criterion)
+    with pytest.raises(Exception):
+        v8DetectionLoss(model)([m.clone() for m in maps], batch)      # default on CPU maps: loud, no silent detour
     # the product consumes NHWC memory: feed channels_last-strided tensors like the engine does
     feats = [m.contiguous(memory_format=torch.channels_last).requires_grad_(True) for m in maps]
     loss, items = crit(feats, batch)
