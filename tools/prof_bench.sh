@@ -8,10 +8,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 if [ "$MODE" = stats ]; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench.json 2> $OUT/bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline --no-fwd-leg > $OUT/bench.json 2> $OUT/bench.err
 else
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o run -- python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-graphs > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o run -- python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-fwd-leg --no-graphs > $OUT/bench_$c.json 2> $OUT/bench_$c.err
   done
 fi
 find $OUT -type f | head -30
