@@ -214,6 +214,7 @@ def main():
                 for name, e0, e1, meta in prof:
                     fh.write(json.dumps({"name": name, "ms": round(e0.elapsed_time(e1), 4),
                                          "gflop": round((meta or {}).get("flops", 0) / 1e9, 3) if name.startswith(("sy11_conv2d", "sy11_stem")) else 0,
+                                         "mbytes": round((meta or {}).get("bytes", 0) / 1e6, 3) if name.startswith(("sy11_conv2d", "sy11_stem")) else 0,
                                          "desc": (meta or {}).get("desc") if name.startswith(("sy11_conv2d", "sy11_stem")) else None}) + "\n")
         top = max(fam.items(), key=lambda kv: kv[1]["ms"])
         name, f = top

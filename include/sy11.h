@@ -51,6 +51,22 @@ typedef struct sy11_conv_desc {
 int sy11_version(void);
 const char* sy11_last_error(void);
 
+/* ---- run-time options (no reference counterpart; they stand where the reference has cfg keys / torch switches):
+ *   "deterministic" 0|1   cfg/default.yaml:29 `deterministic`, utils/torch_utils.py:474-492 (ordered reductions instead of
+ *                         floating-point atomics: bit-identical reruns)
+ *   "tune" 0|1            first-call tile autotuner (cf. torch.backends.cudnn.benchmark, utils/torch_utils.py:488)
+ *   "tune_log" 0|1, "igemm_cfg" / "wgrad_cfg" (-1 = automatic, else force one tile configuration), "igemm_korder" 0|1.
+ * Defaults come from the environment (SY11_TUNE, SY11_TUNE_LOG, SY11_IGEMM_CFG, SY11_WGRAD_CFG, SY11_IGEMM_KORDER,
+ * SY11_DETERMINISTIC).  Process-wide; set them between launches, not concurrently with them.                         */
+int sy11_set_option(const char* name, int32_t value);
+int sy11_get_option(const char* name, int32_t* value);
+/* The autotuner's pick tables as a flat array of 16-byte records {u64 problem hash, i32 kind, i32 pick}: export on one
+ * rank, broadcast, import on the others, so every rank of a data-parallel job (engine/trainer.py:217-228) runs the same
+ * kernels.  sy11_tune_export returns the number of bytes needed (pass buf = NULL to size the buffer).                 */
+int64_t sy11_tune_export(void* buf, int64_t capacity_bytes);
+int sy11_tune_import(const void* buf, int64_t bytes);
+int sy11_tune_clear(void);
+
 /* ---- convolution (replaces nn.Conv2d inside Conv.forward / forward_fuse, nn/modules/conv.py:79-83,
  *      and the bare nn.Conv2d heads of Detect, nn/modules/head.py:44-55) -------------------------------- */
 
@@ -194,9 +210,12 @@ int sy11_cast(int32_t src_dtype, int32_t dst_dtype, int64_t n, const void* src, 
  * p (f32, B*heads*N*N) receives the attention probabilities (kept for backward).                            */
 int sy11_attention_fwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
                        int32_t qkv_ld, void* o, int32_t o_ld, float* p, void* stream);
+/* workspace: caller-allocated, sy11_attention_workspace_bytes(B, N, heads) bytes (f32 B*heads*N*N: the generic kernels
+ * stage dS there; the MFMA path only uses its first B*heads*N floats for the per-query row sums).                    */
 int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
                        int32_t qkv_ld, const float* p, const void* d_o, int32_t do_ld, void* dqkv, int32_t dqkv_ld,
                        float* workspace, void* stream);
+size_t sy11_attention_workspace_bytes(int32_t B, int32_t N, int32_t heads);
 
 /* ---- Detect decode + NMS (nn/modules/head.py:100-131; utils/ops.py:181-332 + torchvision.ops.nms) ------- */
 /* maps: 3 NHWC f32 maps (B,H_l,W_l,64+nc); out: (B, 4+nc, A) f32 exactly as Detect._inference returns it.   */

@@ -838,6 +838,10 @@ extern "C" int sy11_attention_fwd(int32_t dtype, int32_t B, int32_t N, int32_t h
   return SY11_OK;
 }
 
+extern "C" size_t sy11_attention_workspace_bytes(int32_t B, int32_t N, int32_t heads) {
+  return (B <= 0 || N <= 0 || heads <= 0) ? 0 : (size_t)B * heads * N * N * sizeof(float);
+}
+
 extern "C" int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
                                   int32_t qkv_ld, const float* p, const void* d_o, int32_t do_ld, void* dqkv, int32_t dqkv_ld,
                                   float* workspace, void* stream) {

@@ -1,5 +1,7 @@
 // core.hip — version / thread-local error string of libsy11.
 #include "common.h"
+#include "tune.h"
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 
@@ -12,3 +14,87 @@ void sy11_set_error(const char* fmt, ...) {
 
 extern "C" int sy11_version(void) { return SY11_VERSION; }
 extern "C" const char* sy11_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------ run-time options
+static int g_opt[OPT_COUNT];
+static std::once_flag g_opt_once;
+static const char* const kOptName[OPT_COUNT] = {"tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder", "deterministic", "igemm_deep"};
+static void opt_init() {
+  auto env = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+  g_opt[OPT_TUNE] = env("SY11_TUNE", 1) != 0;
+  g_opt[OPT_TUNE_LOG] = env("SY11_TUNE_LOG", 0) != 0;
+  g_opt[OPT_IGEMM_CFG] = env("SY11_IGEMM_CFG", -1);
+  g_opt[OPT_WGRAD_CFG] = env("SY11_WGRAD_CFG", -1);
+  g_opt[OPT_IGEMM_KORDER] = env("SY11_IGEMM_KORDER", 1);
+  g_opt[OPT_DETERMINISTIC] = env("SY11_DETERMINISTIC", 0) != 0;
+  g_opt[OPT_IGEMM_DEEP] = env("SY11_IGEMM_DEEP", 0);
+}
+int sy11_opt(int which) {
+  std::call_once(g_opt_once, opt_init);
+  return g_opt[which];
+}
+static int opt_index(const char* name) {
+  if (name)
+    for (int i = 0; i < OPT_COUNT; ++i)
+      if (!strcmp(name, kOptName[i])) return i;
+  return -1;
+}
+extern "C" int sy11_set_option(const char* name, int32_t value) {
+  const int i = opt_index(name);
+  SY11_REQUIRE(i >= 0, "set_option: unknown option '%s' (tune, tune_log, igemm_cfg, wgrad_cfg, igemm_korder, deterministic, igemm_deep)", name ? name : "(null)");
+  std::call_once(g_opt_once, opt_init);
+  g_opt[i] = value;
+  return SY11_OK;
+}
+extern "C" int sy11_get_option(const char* name, int32_t* value) {
+  const int i = opt_index(name);
+  SY11_REQUIRE(i >= 0 && value, "get_option: unknown option '%s' or null result pointer", name ? name : "(null)");
+  *value = sy11_opt(i);
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ tuner pick tables
+namespace sy11tune {
+Cache& cache(int kind) {
+  static Cache c[2];
+  return c[kind & 1];
+}
+}  // namespace sy11tune
+
+// records of 16 bytes: {u64 problem hash, i32 kind, i32 pick}
+extern "C" int64_t sy11_tune_export(void* buf, int64_t capacity_bytes) {
+  int64_t n = 0;
+  for (int kind = 0; kind < 2; ++kind) {
+    sy11tune::Cache& c = sy11tune::cache(kind);
+    std::lock_guard<std::mutex> g(c.mu);
+    for (const auto& kv : c.map) {
+      if (buf && (n + 1) * 16 <= capacity_bytes) {
+        unsigned char* p = (unsigned char*)buf + n * 16;
+        const uint64_t h = kv.first;
+        const int32_t k = kind, v = kv.second;
+        memcpy(p, &h, 8); memcpy(p + 8, &k, 4); memcpy(p + 12, &v, 4);
+      }
+      ++n;
+    }
+  }
+  return n * 16;                      // bytes needed (call with buf = NULL to size the buffer)
+}
+extern "C" int sy11_tune_import(const void* buf, int64_t bytes) {
+  SY11_REQUIRE(bytes >= 0 && bytes % 16 == 0 && (buf || bytes == 0), "tune_import: buffer must hold whole 16-byte records");
+  for (int64_t i = 0; i < bytes / 16; ++i) {
+    const unsigned char* p = (const unsigned char*)buf + i * 16;
+    uint64_t h; int32_t k, v;
+    memcpy(&h, p, 8); memcpy(&k, p + 8, 4); memcpy(&v, p + 12, 4);
+    SY11_REQUIRE(k == 0 || k == 1, "tune_import: record %ld has kind %d", (long)i, k);
+    sy11tune::cache(k).put(h, v);
+  }
+  return SY11_OK;
+}
+extern "C" int sy11_tune_clear(void) {
+  for (int kind = 0; kind < 2; ++kind) {
+    sy11tune::Cache& c = sy11tune::cache(kind);
+    std::lock_guard<std::mutex> g(c.mu);
+    c.map.clear();
+  }
+  return SY11_OK;
+}

@@ -167,8 +167,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
     const int rl = ld_row + RPP * i, n = bn0 + rl;
     b_off[i] = (n < a.N && rl < BN) ? n * a.wK * ESZ : (int)OOB;
   }
-  int kt = (ld_chunk * EPC) / a.C;             // tap of this thread's chunk in the current stage
-  int kc = (ld_chunk * EPC) - kt * a.C;        // channel within the tap
+  // (tap, channel-in-tap) of this thread's chunk in the stage about to be issued.  Carried BY VALUE through issue_stage:
+  // captured by reference next to the "memory"-clobbering DMA asm they were kept in scratch memory (r02 ISA inspection:
+  // two scratch_load_dword + s_waitcnt vmcnt(0) at the top of every stage — a ~400-cycle stall in front of each DMA issue
+  // that also drained every LDS-DMA still in flight, so deeper rings could not help)
+  struct KPos { int kt, kc; };
+  KPos kp;
+  kp.kt = (ld_chunk * EPC) / a.C;
+  kp.kc = (ld_chunk * EPC) - kp.kt * a.C;
   const dma_rsrc_t xr = make_dma_rsrc(a.x, a.x_bytes), wr_ = make_dma_rsrc(a.w, a.w_bytes);
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -180,7 +186,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   const bool b_issue = (BN >= RPP) || (wave_u * RPI < BN);         // BN < rows-per-pass: only waves covering real rows issue
   __syncthreads();  // tap tables visible
 
-  auto issue_stage = [&](int stage_idx) {
+  auto issue_stage = [&](int stage_idx, KPos k) -> KPos {
+    int kt = k.kt, kc = k.kc;
     const unsigned sa = smem_base + stage_idx * STAGE + wave_u * (RPI * KB);
     const unsigned sb = sa + A_BYTES;
     const bool kvalid = kt < a.T;
@@ -209,6 +216,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
       while (kc >= a.C) { kc -= a.C; ++kt; }
     }
     }
+    KPos r;
+    r.kt = kt; r.kc = kc;
+    return r;
   };
 
   f32x16 acc[MI][NI];
@@ -282,21 +292,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
       }
     }
   };
-  if (nstage > 0) issue_stage(0);
-  if (NST == 3 && nstage > 1) issue_stage(1);
+  // NST - 1 stages are kept in flight: on the small maps (20x20 / 40x40: 200..800 workgroups, 1..3 per CU) a stage is one
+  // L2 / fabric round trip (~1 us) that nothing else on the CU hides, so the kernel time is (stages x latency) / depth.
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nstage) kp = issue_stage(p, kp);
   for (int s0 = 0; s0 < nstage; s0 += NST) {
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
       const int s = s0 + u;
       if (s < nstage) {
-        if (NST == 3 && s + 1 < nstage) {
+        // stage s must have landed; the (up to NST - 2) stages issued after it may stay outstanding
+        const int later = nstage - 1 - s;
+        if (NST >= 4 && later >= 2) {
+          if (b_issue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (APASS + BPASS)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * APASS) : "memory");
+        } else if (NST >= 3 && later >= 1) {
           if (b_issue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS + BPASS) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS) : "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (s + NST - 1 < nstage && a.debug != 1) issue_stage((u + NST - 1) % NST);
+        if (s + NST - 1 < nstage && a.debug != 1) kp = issue_stage((u + NST - 1) % NST, kp);
         if (a.debug != 2) consume(smem + u * STAGE);
       }
     }
@@ -479,7 +497,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // cfg: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x128 (pixels x channels per workgroup), all with 64-byte K stages;
 // 4..6 = the first three with 128-byte K stages (half the barriers per K, 2 workgroups per CU instead of 4)
 // 7, 8 = persistent 1x1 kernel (igemm1x1.hip) with 128 / 64 channels per workgroup
-constexpr int IGEMM_NCFG = 9;
+// 9..11 = the first three with a 4-deep ring of 64-byte stages (3 stages in flight); 12..14 = 128-byte stages, 3-deep ring
+constexpr int IGEMM_NCFG = 15;
 int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq, int M, int N, int K, int x_ld,
                           int y_ld, int stat_slots, int stat_stride, unsigned x_bytes, unsigned w_bytes, int epi, int nostore, int bn,
                           hipStream_t st, const float* bias);
@@ -490,13 +509,18 @@ static int epi_code(const IgemmArgs& a) {
 template <typename T>
 static bool cfg_legal(const IgemmArgs& a, int cfg) {
   if (cfg < 0 || cfg >= IGEMM_NCFG) return false;
-  if (cfg >= 7) {
+  if (cfg == 7 || cfg == 8) {
     const int epi = epi_code(a), bn = cfg == 7 ? 128 : 64;
     if (std::is_same<T, float>::value || a.T != 1 || a.tap_dy[0] || a.tap_dx[0] || a.sy != 1 || a.sx != 1 || !a.dense_out || !a.vec_out) return false;
     if ((epi != 0 && epi != 1 && epi != 8 && epi != 6) || a.K % 32 || a.K != a.C || a.wK != a.K || a.N % 8 || a.debug) return false;
     if (cfg == 7 && a.N <= 64) return false;                 // 128 channels per workgroup only when there are that many
     if (cfg == 8 && a.N <= 32) return false;
     return (size_t)(a.K / 32) * 64 * (bn + 256) + (size_t)128 * bn * 2 <= 150 * 1024;
+  }
+  if (cfg >= 9) {                                      // deep rings: f16, the training / inference epilogues only (code size)
+    const int epi = epi_code(a);
+    if (!std::is_same<T, _Float16>::value || (epi != 0 && epi != 1 && epi != 8 && epi != 6)) return false;
+    return cfg >= 12 ? a.K >= 384 : a.K >= 128;        // at least as many stages as the ring is deep
   }
   if (cfg >= 4) return a.K >= 256;                     // long stages only pay with enough K to amortise them
   if (cfg != 3) return true;
@@ -507,17 +531,18 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
 
 template <typename T>
 static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
-  if (cfg >= 7)
+  if (cfg == 7 || cfg == 8)
     return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
                                  a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st, a.bias);
   const int bm = cfg == 3 ? 256 : 128;
-  const int tile = cfg >= 4 ? cfg - 4 : cfg;
+  const int tile = cfg >= 12 ? cfg - 12 : (cfg >= 9 ? cfg - 9 : (cfg >= 4 ? cfg - 4 : cfg));
   const int bn = tile == 1 ? 64 : (tile == 2 ? 32 : 128);
   a.tiles_n = cdiv(a.N, bn);
   const long nwg = (long)cdiv(a.M, bm) * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg), block(256);
-  const int variant = cfg >= 4 ? 0 : 1;          // 0 = 128-byte stages x2 (2 WG/CU), 1 = 64-byte stages x2 (4 WG/CU)
+  // 0 = 128-byte stages x2 (2 WG/CU), 1 = 64-byte stages x2 (4 WG/CU), 2 = 64-byte stages x4, 3 = 128-byte stages x3
+  const int variant = cfg >= 12 ? 3 : (cfg >= 9 ? 2 : (cfg >= 4 ? 0 : 1));
   // epilogue specialisation: the common flag sets get branch-free code, anything else the runtime-flag build (EPI = -1)
   int epi = (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
             ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
@@ -526,7 +551,11 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
 #define SY11_IGV(BNN, WMM, WNN, EE)                                                                                  \
   do {                                                                                                               \
     if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, 128, BNN, WMM, WNN, 128, 2, EE>), grid, block, 0, st, a);  \
-    else hipLaunchKernelGGL((igemm_kernel<T, 128, BNN, WMM, WNN, 64, 2, EE>), grid, block, 0, st, a);                \
+    else if (variant == 1) hipLaunchKernelGGL((igemm_kernel<T, 128, BNN, WMM, WNN, 64, 2, EE>), grid, block, 0, st, a); \
+    else if constexpr (std::is_same<T, _Float16>::value && (EE == 0 || EE == 1 || EE == 8 || EE == 6)) {            \
+      if (variant == 2) hipLaunchKernelGGL((igemm_kernel<T, 128, BNN, WMM, WNN, 64, 4, EE>), grid, block, 0, st, a);  \
+      else hipLaunchKernelGGL((igemm_kernel<T, 128, BNN, WMM, WNN, 128, 3, EE>), grid, block, 0, st, a);             \
+    }                                                                                                                \
   } while (0)
 #define SY11_IG(BNN, WMM, WNN)                                   \
   do {                                                           \
@@ -558,20 +587,18 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
 
 template <typename T>
 static int select_and_launch(IgemmArgs& a, hipStream_t st) {
-  static int dbg = -1, forced = -2;
+  static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("SY11_IGEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-  if (forced == -2) { const char* e = getenv("SY11_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
+  const int forced = sy11_opt(OPT_IGEMM_CFG);
   a.debug = dbg;
-  static int korder = -1;
-  if (korder < 0) { const char* e = getenv("SY11_IGEMM_KORDER"); korder = e ? atoi(e) : 1; }
-  a.chan_major = korder;
+  a.chan_major = sy11_opt(OPT_IGEMM_KORDER);
   // static heuristic: widest channel tile the layer fills; small maps (20x20 / 40x40) narrow it until the grid covers the chip
   int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   while (bn > 32 && (long)cdiv(a.M, 128) * cdiv(a.N, bn) < 512) bn >>= 1;
   int cfg = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
   if (forced >= 0 && cfg_legal<T>(a, forced)) return launch_cfg<T>(a, st, forced);
   if (sy11tune::enabled() && dbg == 0) {
-    static sy11tune::Cache cache;
+    sy11tune::Cache& cache = sy11tune::cache(0);
     const int key[] = {(int)sizeof(T), a.M, a.N, a.K, a.C, a.T, a.sy, a.sx, a.IW, a.OW, a.x_ld, a.y_ld, a.dense_out,
                        (int)(a.flags & SY11_EPI_OUT_F32)};
     const uint64_t h = sy11tune::hash(key, (int)(sizeof(key) / sizeof(int)));
@@ -581,7 +608,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
     } else if (!sy11tune::capturing(st)) {
       int cands[IGEMM_NCFG], nc = 0;
       for (int c = 0; c < IGEMM_NCFG; ++c) {
-        const int ct = c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c);
+        const int ct = c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c)));
         const int cbn = ct == 1 ? 64 : (ct == 2 ? 32 : 128);
         if (cbn > 32 && cbn >= 2 * a.N) continue;                        // tile more than twice the channel count: pure waste
         if (cfg_legal<T>(a, c)) cands[nc++] = c;
@@ -594,6 +621,17 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
       const int best = sy11tune::pick(cands, nc, [&](int c) { return launch_cfg<T>(t, st, c); }, st, "igemm", key,
                                       (int)(sizeof(key) / sizeof(int)));
       if (best >= 0) { cache.put(h, best); cfg = best; }
+    }
+  }
+  // ring depth.  The tuner times a problem back to back on hot caches, where a stage's DMA returns from the local L2 in a few
+  // hundred cycles and ring depth does not matter; inside the model every layer reads what ANOTHER kernel (other XCDs) just
+  // wrote, a stage is a fabric round trip, and the small maps (1..3 workgroups per CU) have nothing else to hide it with.
+  const int deep = sy11_opt(OPT_IGEMM_DEEP);
+  if (deep > 0) {
+    const long nwg = (long)cdiv(a.M, 128) * cdiv(a.N, cfg % 4 == 1 ? 64 : (cfg % 4 == 2 ? 32 : 128));
+    if (deep >= 2 || nwg <= 1024) {
+      const int up = cfg <= 2 ? cfg + 9 : ((cfg >= 4 && cfg <= 6) ? cfg + 8 : -1);
+      if (up >= 0 && cfg_legal<T>(a, up)) cfg = up;
     }
   }
   return launch_cfg<T>(a, st, cfg);

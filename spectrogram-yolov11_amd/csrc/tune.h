@@ -14,18 +14,15 @@
 #include <mutex>
 #include <unordered_map>
 
+// process-wide options (core.hip): defaults come from the environment (SY11_TUNE, SY11_TUNE_LOG, SY11_IGEMM_CFG,
+// SY11_WGRAD_CFG, SY11_IGEMM_KORDER, SY11_DETERMINISTIC), sy11_set_option() changes them at run time
+enum Sy11Opt { OPT_TUNE = 0, OPT_TUNE_LOG, OPT_IGEMM_CFG, OPT_WGRAD_CFG, OPT_IGEMM_KORDER, OPT_DETERMINISTIC, OPT_IGEMM_DEEP, OPT_COUNT };
+int sy11_opt(int which);
+
 namespace sy11tune {
 
-inline bool enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SY11_TUNE"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
-inline bool logging() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SY11_TUNE_LOG"); v = (e && e[0] != '0') ? 1 : 0; }
-  return v == 1;
-}
+inline bool enabled() { return sy11_opt(OPT_TUNE) == 1; }
+inline bool logging() { return sy11_opt(OPT_TUNE_LOG) == 1; }
 inline bool capturing(hipStream_t st) {
   hipStreamCaptureStatus s = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &s) != hipSuccess) { (void)hipGetLastError(); return true; }   // unknown -> do not measure
@@ -52,6 +49,10 @@ struct Cache {
     map[k] = v;
   }
 };
+// the process's pick tables (core.hip): kind 0 = igemm (fwd / dgrad), 1 = wgrad.  One table per kind so that the picks
+// can be exported / imported as a whole (sy11_tune_export / sy11_tune_import: every rank of a data-parallel job runs the
+// kernels rank 0 measured).
+Cache& cache(int kind);
 
 // run(cand) launches candidate `cand` on `st` and returns 0 on success.  Returns the fastest candidate, or -1 if
 // nothing could be measured.

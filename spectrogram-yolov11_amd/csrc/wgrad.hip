@@ -475,12 +475,11 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
     }
   // static heuristic (r01 sweeps): 128-wide tiles unless the map is small, one round of workgroups, >= 512 pixels per split
   int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 4 : 0) + 2;
-  static int forced = -2;
-  if (forced == -2) { const char* e = getenv("SY11_WGRAD_CFG"); forced = e ? atoi(e) : -1; }
+  const int forced = sy11_opt(OPT_WGRAD_CFG);
   const int ncfg = d->dtype == SY11_F32 ? 8 : WGRAD_NCFG;
   if (forced >= 0 && forced < ncfg) return wgrad_launch_cfg(a, d->dtype, st, forced);
   if (sy11tune::enabled()) {
-    static sy11tune::Cache cache;
+    sy11tune::Cache& cache = sy11tune::cache(1);
     static float* scratch = nullptr;
     static size_t scratch_elems = 0;
     const int key[] = {d->dtype, a.M, a.N, a.K, a.C, a.sy, a.sx, a.IW, a.OW, a.x_ld, a.dy_ld};

@@ -82,8 +82,16 @@ SIGNATURES = {
     "sy11_image_letterbox": [_i32] * 12 + [_vp, _vp, _vp],
     "sy11_image_mosaic_warp": [_i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
 }
+SIGNATURES.update({
+    "sy11_set_option": [C.c_char_p, _i32],
+    "sy11_get_option": [C.c_char_p, C.POINTER(C.c_int32)],
+    "sy11_tune_import": [_vp, _i64],
+    "sy11_tune_clear": [],
+})
 OTHER = {"sy11_version": ([], C.c_int), "sy11_last_error": ([], C.c_char_p),
-         "sy11_nms_workspace_bytes": ([_i32], C.c_size_t)}
+         "sy11_nms_workspace_bytes": ([_i32], C.c_size_t),
+         "sy11_attention_workspace_bytes": ([_i32, _i32, _i32], C.c_size_t),
+         "sy11_tune_export": ([_vp, _i64], C.c_int64)}
 
 _lib = None
 
@@ -136,3 +144,28 @@ def call(name: str, *args):
     check(getattr(load(), name)(*args), name)
     e1.record()
     PROFILE.append((name, e0, e1, PROFILE_META))
+
+
+def set_option(name: str, value: int):
+    """sy11_set_option: "deterministic", "tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder"."""
+    check(load().sy11_set_option(name.encode(), int(value)), "sy11_set_option")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int32(0)
+    check(load().sy11_get_option(name.encode(), C.byref(v)), "sy11_get_option")
+    return int(v.value)
+
+
+def tune_export() -> bytes:
+    """The autotuner's pick tables as bytes (16-byte records), for broadcasting to the other ranks."""
+    lib = load()
+    n = int(lib.sy11_tune_export(None, 0))
+    buf = C.create_string_buffer(max(n, 1))
+    n2 = int(lib.sy11_tune_export(buf, n))
+    return buf.raw[:min(n, n2)]
+
+
+def tune_import(blob: bytes):
+    buf = C.create_string_buffer(bytes(blob), len(blob)) if blob else None
+    check(load().sy11_tune_import(buf, len(blob)), "sy11_tune_import")

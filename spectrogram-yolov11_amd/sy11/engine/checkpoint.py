@@ -32,10 +32,18 @@ class IterableSimpleNamespace(types.SimpleNamespace):
         return getattr(self, key, default)
 
 
+class _InertHolder(nn.Module):
+    """Unpickling target for reference classes whose behaviour lives inside the fused HIP criterion here."""
+
+    def forward(self, *a, **k):
+        from .. import _lib
+        raise _lib.Sy11Error(f"{type(self).__name__} is a checkpoint placeholder: the criterion runs as sy11.utils.loss.v8DetectionLoss")
+
+
 def _class_table():
     from ..nn import tasks
     from ..nn.modules import block, conv, head
-    from ..utils import loss, tal
+    from ..utils import loss
     t = {("ultralytics.nn.tasks", n): getattr(tasks, n) for n in ("DetectionModel", "BaseModel")}
     for mod, names in ((conv, ("Conv", "DWConv", "DDWConv", "Concat", "Fusion", "GCT", "WeightedSpatialAttention")),
                        (block, ("DFL", "SPPF", "C2f", "C3", "C3k", "C3k2", "Bottleneck", "Attention", "PSABlock", "C2PSA")),
@@ -44,11 +52,12 @@ def _class_table():
             t[("ultralytics.nn.modules." + mod.__name__.rsplit(".", 1)[1], n)] = getattr(mod, n)
             t[("ultralytics.nn.modules", n)] = getattr(mod, n)
     t[("ultralytics.utils", "IterableSimpleNamespace")] = IterableSimpleNamespace
-    for n in ("v8DetectionLoss", "BboxLoss", "DFLoss"):
-        if hasattr(loss, n):
-            t[("ultralytics.utils.loss", n)] = getattr(loss, n)
-    if hasattr(tal, "TaskAlignedAssigner"):
-        t[("ultralytics.utils.tal", "TaskAlignedAssigner")] = tal.TaskAlignedAssigner
+    # a reference model pickled after its first loss call carries `criterion` (v8DetectionLoss with its BboxLoss / DFLoss /
+    # TaskAlignedAssigner children).  None of that state is used here — the criterion is rebuilt by init_criterion() — so the
+    # children unpickle into inert holders and `criterion` is dropped by load_checkpoint's caller on first use.
+    t[("ultralytics.utils.loss", "v8DetectionLoss")] = loss.v8DetectionLoss
+    for mod, n in (("ultralytics.utils.loss", "BboxLoss"), ("ultralytics.utils.loss", "DFLoss"), ("ultralytics.utils.tal", "TaskAlignedAssigner")):
+        t[(mod, n)] = type(n, (_InertHolder,), {})
     return t
 
 

@@ -63,6 +63,7 @@ class FlatState:
                 v = _view_like(self.flat[off:off + n], p)
                 v.copy_(p.data)
                 p.data = v
+                p._sy11_owner = self.flat          # in-place updates of the flat buffer invalidate per-parameter caches (conv.working_filter)
                 off += padded(n)
             self.group_slices.append((start, off))
         bufs = [b for b in model.buffers() if b.dtype.is_floating_point]

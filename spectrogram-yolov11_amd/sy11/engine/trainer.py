@@ -147,13 +147,16 @@ class DetectionTrainer:
                 g["lr"] = g["initial_lr"] * self.lf(start_epoch)
             self.ni = start_epoch * self.nb
             self.last_opt_step = self.ni - 1
-        best, stale, history = -1.0, 0, []
+        # resume_training() restores the best fitness so far (trainer.py:727-745): a worse first epoch must not replace best.pt
+        best, stale, history = float(getattr(self, "best_fitness", None) or -1.0), 0, []
+        mosaic_closed = False
         save_dir = Path(save_dir) if save_dir else None
         if save_dir and rank0:
             save_dir.mkdir(parents=True, exist_ok=True)
         for epoch in range(start_epoch, epochs):
-            if epoch == epochs - close_mosaic and hasattr(train_loader.dataset, "close_mosaic"):
-                train_loader.dataset.close_mosaic(train_loader.dataset.hyp)       # trainer.py:341-343
+            if not mosaic_closed and epoch >= epochs - close_mosaic and hasattr(train_loader.dataset, "close_mosaic"):
+                train_loader.dataset.close_mosaic(train_loader.dataset.hyp)       # trainer.py:341-343; `>=` + latch: a run resumed
+                mosaic_closed = True                                              # past that epoch closes it at once (trainer.py:752-756)
             if hasattr(train_loader, "set_epoch"):
                 train_loader.set_epoch(epoch)
             tloss = None
@@ -176,7 +179,15 @@ class DetectionTrainer:
                 stale = 0 if rec["fitness"] >= best else stale + 1               # EarlyStopping (utils/torch_utils.py:713-757)
                 best = max(best, rec["fitness"])
             history.append(rec)
-            if patience and stale >= patience:
+            self.best_fitness = best
+            stop = bool(patience and stale >= patience)
+            if self.world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+                # only rank 0 validates, so only rank 0 knows: every rank must leave the loop together, or the others hang in
+                # the next epoch's gradient all-reduce (trainer.py:456-461 broadcasts the same flag)
+                flag = [stop]
+                torch.distributed.broadcast_object_list(flag, 0)
+                stop = bool(flag[0])
+            if stop:
                 break
         return history
 
@@ -192,6 +203,8 @@ class DetectionTrainer:
             self.ema.ema.load_state_dict(ckpt["ema"].float().state_dict())      # in place: the flat EMA buffers keep their views
             self.ema.updates = ckpt.get("updates", 0)
         self.epoch = start_epoch
+        bf = ckpt.get("best_fitness")
+        self.best_fitness = float(bf) if bf is not None else None          # fit() seeds its `best` from this
         return start_epoch
 
     def _load_optimizer_state(self, osd):

@@ -38,7 +38,10 @@ def _int(v):
 def working_filter(holder: nn.Module, w: torch.Tensor, dtype: torch.dtype, force: bool = False) -> torch.Tensor:
     """[O][KH][KW][I] tensor of ``dtype`` for parameter ``w``; cached until the parameter is modified in place
     (``force``: always re-derive — used under hipGraph capture, where the cast must be part of the replayed work)."""
-    key = (w._version, w.data_ptr(), dtype, w.device)
+    # a parameter re-homed into a flat buffer (engine/flat.py) is a `.data` view of it: the fused optimizer / FlatEMA mutate the
+    # FLAT tensor, which bumps the flat buffer's version counter, never the parameter's own — key on both
+    owner = getattr(w, "_sy11_owner", None)
+    key = (w._version, -1 if owner is None else owner._version, w.data_ptr(), dtype, w.device)
     cache = holder.__dict__.get("_sy11_wcache")
     if not force and cache is not None and cache[0] == key:
         return cache[1]

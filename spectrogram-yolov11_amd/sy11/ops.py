@@ -252,8 +252,10 @@ def attention_fwd(qkv, heads, kd, hd, o, p):
     return o
 
 
-def attention_bwd(qkv, heads, kd, hd, p, d_o, dqkv, ws):
+def attention_bwd(qkv, heads, kd, hd, p, d_o, dqkv, ws=None):
     B, H, W, _ = qkv.shape
+    if ws is None:                                   # caller-owned scratch, sized by the library's own query
+        ws = torch.empty(_lib.load().sy11_attention_workspace_bytes(B, H * W, heads) // 4, dtype=torch.float32, device=qkv.device)
     call("sy11_attention_bwd", dt_code(qkv.dtype), B, H * W, heads, kd, hd, _p(qkv), view_ld(qkv), _p(p), _p(d_o),
          view_ld(d_o), _p(dqkv), view_ld(dqkv), _p(ws), _stream())
     return dqkv

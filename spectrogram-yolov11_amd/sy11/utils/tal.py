@@ -1,130 +1,44 @@
-"""Task-aligned assigner and anchor/box codecs with the reference's names (ultralytics/utils/tal.py:
-TaskAlignedAssigner :14-296, make_anchors :334-346, dist2bbox :349-358, bbox2dist :361-364).
-Runs as device tensor ops on the MI355X ("PyTorch-ROCm ops acceptable initially"; fused HIP assigner is
-a §8(f) next row).  Gotchas kept: SURVEY §8(g) item 10."""
+"""Anchor grid and box <-> side-distance codecs under the reference's names (ultralytics/utils/tal.py: make_anchors
+:334-346, dist2bbox :349-358, bbox2dist :361-364) — host-side helpers for callers that want the tables as tensors.
+
+The reference's ``TaskAlignedAssigner`` (tal.py:14-296) has no tensor-op counterpart here: assignment runs inside the fused
+HIP criterion (csrc/loss.hip ``loss_assign_*``, entered through ``sy11.utils.loss.v8DetectionLoss``), and Detect's decode is
+``sy11_detect_decode``.  The CPU restatement of the assigner that the parity tests check against is oracle/loss_ref.py."""
 from __future__ import annotations
 
 import torch
-import torch.nn as nn
-
-from .metrics import bbox_iou
 
 
-class TaskAlignedAssigner(nn.Module):
-    def __init__(self, topk=13, num_classes=80, alpha=1.0, beta=6.0, eps=1e-9):
-        super().__init__()
-        self.topk, self.num_classes, self.bg_idx = topk, num_classes, num_classes
-        self.alpha, self.beta, self.eps = alpha, beta, eps
-
-    @torch.no_grad()
-    def forward(self, pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt):
-        self.bs = pd_scores.shape[0]
-        self.n_max_boxes = gt_bboxes.shape[1]
-        if self.n_max_boxes == 0:
-            return (torch.full_like(pd_scores[..., 0], self.bg_idx), torch.zeros_like(pd_bboxes),
-                    torch.zeros_like(pd_scores), torch.zeros_like(pd_scores[..., 0]), torch.zeros_like(pd_scores[..., 0]))
-        return self._forward(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt)
-
-    def _forward(self, pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt):
-        mask_pos, align_metric, overlaps = self.get_pos_mask(pd_scores, pd_bboxes, gt_labels, gt_bboxes, anc_points, mask_gt)
-        target_gt_idx, fg_mask, mask_pos = self.select_highest_overlaps(mask_pos, overlaps, self.n_max_boxes)
-        target_labels, target_bboxes, target_scores = self.get_targets(gt_labels, gt_bboxes, target_gt_idx, fg_mask)
-        align_metric *= mask_pos
-        pos_align = align_metric.amax(dim=-1, keepdim=True)
-        pos_ov = (overlaps * mask_pos).amax(dim=-1, keepdim=True)
-        norm = (align_metric * pos_ov / (pos_align + self.eps)).amax(-2).unsqueeze(-1)
-        return target_labels, target_bboxes, target_scores * norm, fg_mask.bool(), target_gt_idx
-
-    def get_pos_mask(self, pd_scores, pd_bboxes, gt_labels, gt_bboxes, anc_points, mask_gt):
-        mask_in_gts = self.select_candidates_in_gts(anc_points, gt_bboxes)
-        align_metric, overlaps = self.get_box_metrics(pd_scores, pd_bboxes, gt_labels, gt_bboxes, mask_in_gts * mask_gt)
-        mask_topk = self.select_topk_candidates(align_metric, topk_mask=mask_gt.expand(-1, -1, self.topk).bool())
-        return mask_topk * mask_in_gts * mask_gt, align_metric, overlaps
-
-    def get_box_metrics(self, pd_scores, pd_bboxes, gt_labels, gt_bboxes, mask_gt):
-        na = pd_bboxes.shape[-2]
-        mask_gt = mask_gt.bool()
-        overlaps = torch.zeros([self.bs, self.n_max_boxes, na], dtype=pd_bboxes.dtype, device=pd_bboxes.device)
-        bbox_scores = torch.zeros([self.bs, self.n_max_boxes, na], dtype=pd_scores.dtype, device=pd_scores.device)
-        ind0 = torch.arange(self.bs, device=pd_scores.device).view(-1, 1).expand(-1, self.n_max_boxes)
-        ind1 = gt_labels.squeeze(-1).long()
-        bbox_scores[mask_gt] = pd_scores[ind0, :, ind1][mask_gt]
-        pd_boxes = pd_bboxes.unsqueeze(1).expand(-1, self.n_max_boxes, -1, -1)[mask_gt]
-        gt_boxes = gt_bboxes.unsqueeze(2).expand(-1, -1, na, -1)[mask_gt]
-        overlaps[mask_gt] = self.iou_calculation(gt_boxes, pd_boxes)
-        return bbox_scores.pow(self.alpha) * overlaps.pow(self.beta), overlaps
-
-    def iou_calculation(self, gt_bboxes, pd_bboxes):
-        return bbox_iou(gt_bboxes, pd_bboxes, xywh=False, CIoU=True).squeeze(-1).clamp_(0)
-
-    def select_topk_candidates(self, metrics, largest=True, topk_mask=None):
-        topk_metrics, topk_idxs = torch.topk(metrics, self.topk, dim=-1, largest=largest)
-        if topk_mask is None:
-            topk_mask = (topk_metrics.max(-1, keepdim=True)[0] > self.eps).expand_as(topk_idxs)
-        topk_idxs.masked_fill_(~topk_mask, 0)
-        count = torch.zeros(metrics.shape, dtype=torch.int8, device=topk_idxs.device)
-        ones = torch.ones_like(topk_idxs[:, :, :1], dtype=torch.int8, device=topk_idxs.device)
-        for k in range(self.topk):
-            count.scatter_add_(-1, topk_idxs[:, :, k:k + 1], ones)
-        count.masked_fill_(count > 1, 0)
-        return count.to(metrics.dtype)
-
-    def get_targets(self, gt_labels, gt_bboxes, target_gt_idx, fg_mask):
-        batch_ind = torch.arange(end=self.bs, dtype=torch.int64, device=gt_labels.device)[..., None]
-        target_gt_idx = target_gt_idx + batch_ind * self.n_max_boxes
-        target_labels = gt_labels.long().flatten()[target_gt_idx]
-        target_bboxes = gt_bboxes.view(-1, gt_bboxes.shape[-1])[target_gt_idx]
-        target_labels.clamp_(0)
-        target_scores = torch.zeros((target_labels.shape[0], target_labels.shape[1], self.num_classes), dtype=torch.int64,
-                                    device=target_labels.device)
-        target_scores.scatter_(2, target_labels.unsqueeze(-1), 1)
-        fg_scores_mask = fg_mask[:, :, None].repeat(1, 1, self.num_classes)
-        return target_labels, target_bboxes, torch.where(fg_scores_mask > 0, target_scores, 0)
-
-    @staticmethod
-    def select_candidates_in_gts(xy_centers, gt_bboxes, eps=1e-9):
-        n_anchors = xy_centers.shape[0]
-        bs, n_boxes, _ = gt_bboxes.shape
-        lt, rb = gt_bboxes.view(-1, 1, 4).chunk(2, 2)
-        deltas = torch.cat((xy_centers[None] - lt, rb - xy_centers[None]), dim=2).view(bs, n_boxes, n_anchors, -1)
-        return deltas.amin(3).gt_(eps)
-
-    @staticmethod
-    def select_highest_overlaps(mask_pos, overlaps, n_max_boxes):
-        fg_mask = mask_pos.sum(-2)
-        if fg_mask.max() > 1:
-            multi = (fg_mask.unsqueeze(1) > 1).expand(-1, n_max_boxes, -1)
-            best = overlaps.argmax(1)
-            is_max = torch.zeros(mask_pos.shape, dtype=mask_pos.dtype, device=mask_pos.device)
-            is_max.scatter_(1, best.unsqueeze(1), 1)
-            mask_pos = torch.where(multi, is_max, mask_pos).float()
-            fg_mask = mask_pos.sum(-2)
-        return mask_pos.argmax(-2), fg_mask, mask_pos
+def _level_hw(level):
+    if torch.is_tensor(level):
+        return int(level.shape[-2]), int(level.shape[-1])
+    h, w = level
+    return int(h), int(w)
 
 
 def make_anchors(feats, strides, grid_cell_offset=0.5):
-    """Cell-centre anchor points + per-anchor stride.  ``feats``: maps (NCHW-shaped) or [(h, w), ...]."""
-    pts, st = [], []
-    ref = feats[0]
-    dtype, device = (ref.dtype, ref.device) if isinstance(ref, torch.Tensor) else (torch.float32, None)
-    for i, stride in enumerate(strides):
-        h, w = feats[i].shape[2:] if isinstance(feats[i], torch.Tensor) else (int(feats[i][0]), int(feats[i][1]))
-        sx = torch.arange(end=w, device=device, dtype=dtype) + grid_cell_offset
-        sy = torch.arange(end=h, device=device, dtype=dtype) + grid_cell_offset
-        sy, sx = torch.meshgrid(sy, sx, indexing="ij")
-        pts.append(torch.stack((sx, sy), -1).view(-1, 2))
-        st.append(torch.full((h * w, 1), float(stride), dtype=dtype, device=device))
-    return torch.cat(pts), torch.cat(st)
+    """-> (points (A, 2) as (x, y) cell centres in grid units, stride (A, 1)); levels concatenated in the given order,
+    cells row-major inside a level.  ``feats``: maps (.., H, W) or (h, w) pairs."""
+    first = feats[0]
+    kw = dict(dtype=first.dtype, device=first.device) if torch.is_tensor(first) else dict(dtype=torch.float32)
+    points, per_anchor_stride = [], []
+    for level, s in zip(feats, strides):
+        h, w = _level_hw(level)
+        cell = torch.arange(h * w, **{**kw, "dtype": torch.int64})
+        xy = torch.stack((cell % w, cell // w), 1).to(kw["dtype"]) + grid_cell_offset
+        points.append(xy)
+        per_anchor_stride.append(xy.new_full((h * w, 1), float(s)))
+    return torch.cat(points), torch.cat(per_anchor_stride)
 
 
 def dist2bbox(distance, anchor_points, xywh=True, dim=-1):
-    lt, rb = distance.chunk(2, dim)
-    x1y1, x2y2 = anchor_points - lt, anchor_points + rb
-    if xywh:
-        return torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), dim)
-    return torch.cat((x1y1, x2y2), dim)
+    """(left, top, right, bottom) distances from an anchor point -> box (xywh centre form, or xyxy corners)."""
+    near, far = torch.split(distance, 2, dim)
+    lo, hi = anchor_points - near, anchor_points + far
+    return torch.cat((0.5 * (lo + hi), hi - lo) if xywh else (lo, hi), dim)
 
 
 def bbox2dist(anchor_points, bbox, reg_max):
-    x1y1, x2y2 = bbox.chunk(2, -1)
-    return torch.cat((anchor_points - x1y1, x2y2 - anchor_points), -1).clamp_(0, reg_max - 0.01)
+    """xyxy box -> (left, top, right, bottom) distances from the anchor point, limited to [0, reg_max - 0.01]."""
+    lo, hi = torch.split(bbox, 2, -1)
+    return torch.cat((anchor_points - lo, hi - anchor_points), -1).clamp_(0, reg_max - 0.01)

@@ -179,29 +179,46 @@ def test_ddp_flat_allreduce_gloo_world2(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
-def test_loss_device_ops_match_oracle_on_cpu():
-    """v8DetectionLoss / TaskAlignedAssigner are device-agnostic tensor programs: run them on CPU against the oracle."""
+def test_criterion_host_side_packing_matches_oracle_and_cpu_maps_fail_loudly():
+    """v8DetectionLoss: the target packing (utils/loss.py:194-207) is host-side tensor logic — checked against the oracle on
+    CPU for ragged, empty-image and device-free labels; the criterion itself is HIP only and must refuse CPU maps."""
     from oracle import loss_ref
+    from sy11._lib import Sy11Error
+    from sy11.utils import tal
     from sy11.utils.loss import v8DetectionLoss
-    torch.manual_seed(0)
     nc = 6
-    maps = [torch.randn(2, 64 + nc, h, h) for h in (8, 4, 2)]
-    batch = {"batch_idx": torch.tensor([0., 0., 1.]), "cls": torch.tensor([[1.], [4.], [2.]]),
-             "bboxes": torch.tensor([[0.4, 0.5, 0.5, 0.4], [0.6, 0.6, 0.3, 0.6], [0.5, 0.5, 0.8, 0.5]])}
     det = SimpleNamespace(stride=torch.tensor([8., 16., 32.]), nc=nc, reg_max=16)
     model = SimpleNamespace(args=SimpleNamespace(box=7.5, cls=0.5, dfl=1.5), model=[det],
                             parameters=lambda: iter([torch.zeros(1)]))
-    crit = v8DetectionLoss(model, fused=False)           # the explicit tensor-op formulation (the default is the HIP criterion)
-    with pytest.raises(Exception):
-        v8DetectionLoss(model)([m.clone() for m in maps], batch)      # default on CPU maps: loud, no silent detour
-    # the product consumes NHWC memory: feed channels_last-strided tensors like the engine does
-    feats = [m.contiguous(memory_format=torch.channels_last).requires_grad_(True) for m in maps]
-    loss, items = crit(feats, batch)
-    oloss, oitems = loss_ref.detection_loss([m.clone() for m in maps], batch, nc=nc)
-    assert abs(loss.item() - oloss.item()) < 1e-4 * abs(oloss.item())
-    assert torch.allclose(items, oitems, rtol=1e-4, atol=1e-6)
-    loss.backward()
-    assert all(f.grad is not None and torch.isfinite(f.grad).all() for f in feats)
+    crit = v8DetectionLoss(model)
+    g = torch.Generator().manual_seed(4)
+    for B, ids in ((2, [0, 0, 1]), (4, [3, 0, 3, 3, 1]), (3, [2]), (5, [4, 4, 0, 4, 4, 0, 2])):
+        n = len(ids)
+        bi = torch.tensor(ids, dtype=torch.float32)
+        cls = torch.randint(0, nc, (n, 1), generator=g).float()
+        box = torch.cat((0.2 + 0.6 * torch.rand(n, 2, generator=g), 0.05 + 0.3 * torch.rand(n, 2, generator=g)), 1)
+        scale = torch.tensor([64., 48., 64., 48.])
+        got = crit.preprocess(torch.cat((bi.view(-1, 1), cls, box), 1), B, scale_tensor=scale, batch_idx=bi)
+        ref = loss_ref.pack_targets(bi, cls, box, B, scale)
+        assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-5), (B, ids)
+    assert crit.preprocess(torch.zeros(0, 6), 3, scale_tensor=torch.ones(4)).shape == (3, 0, 5)
+    maps = [torch.randn(2, 64 + nc, h, h) for h in (8, 4, 2)]
+    batch = {"batch_idx": torch.tensor([0., 0., 1.]), "cls": torch.tensor([[1.], [4.], [2.]]),
+             "bboxes": torch.tensor([[0.4, 0.5, 0.5, 0.4], [0.6, 0.6, 0.3, 0.6], [0.5, 0.5, 0.8, 0.5]])}
+    with pytest.raises(Sy11Error):
+        crit(maps, batch)                                   # CPU maps: loud, no tensor-op detour
+    with pytest.raises(Sy11Error):
+        v8DetectionLoss(model, fused=False)
+    # anchor / codec helpers kept under the reference's names
+    pts, st = tal.make_anchors([(8, 6), (4, 3)], [8, 16])
+    rp, rs = R.make_anchors([(8, 6), (4, 3)], [8, 16])
+    assert torch.equal(pts, rp) and torch.equal(st, rs)
+    d = torch.rand(5, 66, 4, generator=g) * 3
+    a = torch.rand(66, 2, generator=g) * 10
+    for xywh in (True, False):
+        assert torch.equal(tal.dist2bbox(d, a, xywh=xywh), R.dist2bbox(d, a, xywh=xywh))
+    bb = tal.dist2bbox(d, a, xywh=False)
+    assert torch.equal(tal.bbox2dist(a, bb, 15), loss_ref.bbox2dist(a, bb, 15))
 
 
 def test_nms_wrapper_candidate_selection_matches_reference_rows(monkeypatch):

@@ -114,6 +114,62 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     close(dw.cpu().permute(0, 3, 1, 2), ref_dw, torch.float32, "conv wgrad", mult=8)
 
 
+CFG_CASES = [
+    # B, C, H, W, N, k, s : every tile configuration must be right on its own, not just the one the tuner would pick
+    (2, 64, 24, 20, 160, 3, 1),      # 3x3, K = 576 (deep rings legal), N not a multiple of the 128 / 64 tiles
+    (3, 256, 12, 12, 96, 1, 1),      # 1x1, K = 256
+    (2, 128, 18, 18, 64, 3, 2),      # stride 2: dgrad = 4 parity launches with 1 / 2 / 2 / 4 taps
+    (4, 32, 40, 40, 32, 1, 1),       # K = 32: shorter than every deep ring (those configurations must refuse, not misbehave)
+]
+
+
+@pytest.mark.parametrize("case", CFG_CASES)
+def test_every_igemm_and_wgrad_tile_configuration(case):
+    """Force each igemm (fwd / dgrad) and wgrad configuration through sy11_set_option and compare with the fp32 CPU conv.
+    A configuration that is not legal for a problem falls back to the heuristic pick (so the result must still be right)."""
+    from sy11 import _lib
+    o = ops()
+    dtype = torch.float16
+    B, Cn, H, W, N, k, s = case
+    p = k // 2
+    x = rnd(B, Cn, H, W, seed=11)
+    w = rnd(N, Cn, k, k, seed=12, scale=1.0 / math.sqrt(Cn * k * k))
+    dy = rnd(B, N, *o.conv_out_hw(H, W, k, s, p), seed=13)
+    xq, wq, dyq = q(x, dtype), q(w, dtype), q(dy, dtype)
+    OH, OW = o.conv_out_hw(H, W, k, s, p)
+    xv, dyv = nhwc(x, dtype), nhwc(dy, dtype)
+    wk = wq.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wt = o.weight_transpose(wk)
+    ref = F.conv2d(xq, wq, None, s, p)
+    ref_dx = torch.nn.grad.conv2d_input((B, Cn, H, W), wq, dyq, s, p)
+    ref_dw = torch.nn.grad.conv2d_weight(xq, (N, Cn, k, k), dyq, s, p)
+    tune0 = _lib.get_option("tune")
+    try:
+        _lib.set_option("tune", 0)
+        for cfg in range(15):
+            _lib.set_option("igemm_cfg", cfg)
+            y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
+            ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+            o.conv2d_fwd(xv, wk, y, k, s, p, stats=(ssum, ssq))
+            close(to_nchw(y), ref, dtype, f"fwd cfg {cfg}")
+            close(ssum.cpu(), ref.sum((0, 2, 3)), dtype, f"stats cfg {cfg}", mult=4 * math.sqrt(B * OH * OW))
+            dx = torch.zeros(B, H, W, Cn, dtype=dtype, device=DEV)
+            o.conv2d_dgrad(dyv, wt, dx, (B, OH, OW, N), k, s, p, accumulate=(s > 1))
+            close(to_nchw(dx), ref_dx, dtype, f"dgrad cfg {cfg}")
+            o.conv2d_dgrad(dyv, wt, dx, (B, OH, OW, N), k, s, p, accumulate=True)
+            close(to_nchw(dx), 2 * ref_dx, dtype, f"dgrad accumulate cfg {cfg}", mult=2)
+        _lib.set_option("igemm_cfg", -1)
+        for cfg in range(12):
+            _lib.set_option("wgrad_cfg", cfg)
+            dw = torch.zeros(N, k, k, Cn, dtype=torch.float32, device=DEV)
+            o.conv2d_wgrad(xv, dyv, dw, k, s, p)
+            close(dw.cpu().permute(0, 3, 1, 2), ref_dw, torch.float32, f"wgrad cfg {cfg}", mult=8)
+    finally:
+        _lib.set_option("igemm_cfg", -1)
+        _lib.set_option("wgrad_cfg", -1)
+        _lib.set_option("tune", tune0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("Cn,H,W", [(64, 8, 8), (24, 7, 5), (5, 6, 6), (256, 20, 20), (128, 13, 27), (512, 3, 12)])
 def test_depthwise_conv(Cn, H, W, dtype):

@@ -101,3 +101,61 @@ def test_flat_state_matches_per_tensor_optimizer(opt):
     for k in ea:
         if ea[k].dtype.is_floating_point:
             assert torch.allclose(ea[k], eb[k], rtol=2e-3, atol=atol), k
+
+
+def test_eager_half_eval_of_the_flat_ema_sees_updated_weights():
+    """Round-1 defect: the f16 working-filter cache of an eager eval forward was keyed on the parameter's own version counter,
+    which in-place updates of the FLAT buffer never bump — every later eager half eval of the EMA (short last batch, rect-val
+    shapes beyond the forward-graph budget) ran with the weights of the first one.  Eval (half) -> train -> eval with a new
+    batch shape must equal a forward of a fresh model loaded with the current EMA weights."""
+    from sy11.nn.tasks import DetectionModel
+    t = make_trainer(graphs=True, amp=True)
+    ema = t.ema.ema
+    ema._sy11_dtype = torch.float16
+    x0 = torch.rand(2, 3, 96, 96, device=DEV)
+    with torch.no_grad():
+        y_before = ema.eval()(x0)[0].float().clone()          # fills every Conv's working-filter cache (eager: no graph cfg yet)
+    for i in range(6):
+        t.train_step(dict(batch(20 + i)))
+    with torch.no_grad():
+        t.ema.ema_state.flat.mul_(1.02)                         # make the change unmistakable (on top of the 6 EMA updates)
+    x1 = torch.rand(3, 3, 64, 96, device=DEV)                  # a shape the EMA has never seen: eager path again
+    with torch.no_grad():
+        got = ema.eval()(x1)[0].float()
+    fresh = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
+    fresh.load_state_dict({k: v.clone() for k, v in ema.state_dict().items()})
+    fresh = fresh.to(DEV).eval()
+    fresh._sy11_dtype = torch.float16
+    with torch.no_grad():
+        want = fresh(x1)[0].float()
+        stale_probe = ema(x0)[0].float()
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    assert not torch.allclose(stale_probe, y_before)           # and the first shape re-casts too
+
+
+def test_resume_restores_best_fitness_and_closes_mosaic_late():
+    """engine/trainer.py:727-756: a resumed run keeps the pre-resume best fitness (a worse first epoch must not replace
+    best.pt) and closes mosaic at once when it restarts inside the last `close_mosaic` epochs."""
+    t = make_trainer(graphs=False)
+    start = t.resume_training({"epoch": 7, "best_fitness": 0.42, "optimizer": None, "ema": None, "updates": 3})
+    assert start == 8 and abs(t.best_fitness - 0.42) < 1e-12
+
+    class DS:
+        hyp = None
+        closed = 0
+
+        def close_mosaic(self, hyp):
+            self.closed += 1
+
+    class Loader:
+        dataset = DS()
+
+        def __len__(self):
+            return 1
+
+        def __iter__(self):
+            return iter([batch(5)])
+    ld = Loader()
+    hist = t.fit(ld, epochs=10, val_batches=None, save_dir=None, close_mosaic=4, start_epoch=8)      # 8 >= 10 - 4: already past
+    assert ld.dataset.closed == 1 and len(hist) == 2
+    assert abs(t.best_fitness - 0.42) < 1e-12                   # no validation ran: the restored value stands
