@@ -133,23 +133,100 @@ def resolve_graph(scale="s", nc=80, ch=3, graph=None):
 # --------------------------------------------------------------------------------------------------
 # primitive ops
 # --------------------------------------------------------------------------------------------------
+# ---- 16-bit execution emulation ---------------------------------------------------------------------------------------------
+# The reference trains under torch autocast (engine/trainer.py:261-271, :378: fp16 operands and stored activations, f32
+# accumulation, f32 master weights); the product's f16 mode has the same rounding points.  Inside ``with emulate_f16():`` this
+# restatement rounds at exactly those points while still computing in f32 on the CPU, so that a 16-bit run can be compared with
+# something that differs from it only by summation order — not by the operand quantisation itself.  Rounding points:
+#   * the input image, every conv / attention operand (filters through a straight-through rounding: master weights and their
+#     gradients stay f32);
+#   * every STORED activation: the raw conv output y, the BN(+SiLU)(+residual) output z (ONE rounding after the residual add:
+#     the product fuses it into the BN pass), the attention output; batch statistics come from the UNROUNDED conv output
+#     (the product takes them from the f32 accumulators); Detect's last 1x1 convs write f32 logits;
+#   * the gradient of every stored activation (a 16-bit tensor too) — scaled by whatever loss scale the caller applies.
+_EMU = {"on": False}
+
+
+class _Stored16(torch.autograd.Function):
+    """A tensor kept in 16-bit memory: value rounded forward, its gradient rounded backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().float()
+
+
+class _Operand16(torch.autograd.Function):
+    """A 16-bit working copy of an f32 master tensor (filters): rounded value, f32 gradient (straight-through)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _st(x):
+    return _Stored16.apply(x) if _EMU["on"] else x
+
+
+def _op(x):
+    return _Operand16.apply(x) if _EMU["on"] else x
+
+
+class emulate_f16:
+    """Context manager switching the restatement to the f16 execution's rounding points (see above)."""
+
+    def __enter__(self):
+        self.prev = _EMU["on"]
+        _EMU["on"] = True
+        return self
+
+    def __exit__(self, *exc):
+        _EMU["on"] = self.prev
+        return False
+
+
 def autopad(k, d=1):
     k = d * (k - 1) + 1 if d > 1 else k
     return k // 2
 
 
-def conv_bn_act(sd, p, x, k=1, s=1, g=1, d=1, act=True, train=False, fused=False):
-    """Conv.forward / forward_fuse.  ``p`` is the state_dict prefix of the Conv module."""
-    w = sd[p + "conv.weight"]
+def conv_bn_act(sd, p, x, k=1, s=1, g=1, d=1, act=True, train=False, fused=False, res=None):
+    """Conv.forward / forward_fuse.  ``p`` is the state_dict prefix of the Conv module; ``res``: a residual the caller adds
+    to the result (Bottleneck / PSABlock shortcuts) — under emulate_f16 the sum is rounded once, as the fused BN pass does."""
+    w = _op(sd[p + "conv.weight"])
     if fused:
         y = F.conv2d(x, w, sd[p + "conv.bias"], s, autopad(k, d), d, g)
-    else:
-        y = F.conv2d(x, w, None, s, autopad(k, d), d, g)
+        y = F.silu(y) if act else y
+        return _st(y if res is None else res + y)
+    y = F.conv2d(x, w, None, s, autopad(k, d), d, g)
+    if not _EMU["on"]:
         y = F.batch_norm(y, sd[p + "bn.running_mean"], sd[p + "bn.running_var"], sd[p + "bn.weight"],
                          sd[p + "bn.bias"], train, BN_MOM, BN_EPS)
-        if train and (p + "bn.num_batches_tracked") in sd:
-            sd[p + "bn.num_batches_tracked"] += 1
-    return F.silu(y) if act else y
+    else:
+        gamma, beta = sd[p + "bn.weight"], sd[p + "bn.bias"]
+        if train:                                      # statistics of the f32 accumulators, normalisation of the stored 16-bit y
+            mean = y.mean((0, 2, 3))
+            var = y.var((0, 2, 3), unbiased=False)
+            with torch.no_grad():
+                n = y.numel() / y.shape[1]
+                sd[p + "bn.running_mean"].mul_(1 - BN_MOM).add_(BN_MOM * mean)
+                sd[p + "bn.running_var"].mul_(1 - BN_MOM).add_(BN_MOM * var * n / max(n - 1, 1))
+        else:
+            mean, var = sd[p + "bn.running_mean"], sd[p + "bn.running_var"]
+        scale = gamma * torch.rsqrt(var + BN_EPS)
+        shift = beta - mean * scale
+        y = _st(y) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if train and (p + "bn.num_batches_tracked") in sd:
+        sd[p + "bn.num_batches_tracked"] += 1
+    y = F.silu(y) if act else y
+    return _st(y if res is None else res + y)
 
 
 def ddwconv(sd, p, x, k, s, d, train=False, fused=False):
@@ -176,13 +253,12 @@ def fusion_eschannel(sd, p, xs):
     """Fusion.forward, 'ESChannel' branch (conv.py:2108-2121): chunks of GCT(cat) plus per-input spatial attention."""
     a = gct(sd, p + ("gsc2." if len(xs) == 2 else "gsc3."), torch.cat(xs, 1))
     chunks = torch.chunk(a, len(xs), dim=1)
-    return sum(c + weighted_spatial_attention(sd, p + "sab.", xs[i]) for i, c in enumerate(chunks))
+    return _st(sum(c + weighted_spatial_attention(sd, p + "sab.", xs[i]) for i, c in enumerate(chunks)))
 
 
 def bottleneck(sd, p, x, c1, c2, shortcut, k=(3, 3), e=0.5, train=False, fused=False):
     y = conv_bn_act(sd, p + "cv1.", x, k[0], 1, train=train, fused=fused)
-    y = conv_bn_act(sd, p + "cv2.", y, k[1], 1, train=train, fused=fused)
-    return x + y if (shortcut and c1 == c2) else y
+    return conv_bn_act(sd, p + "cv2.", y, k[1], 1, train=train, fused=fused, res=x if (shortcut and c1 == c2) else None)
 
 
 def c3k(sd, p, x, c, n=2, shortcut=True, train=False, fused=False):
@@ -213,7 +289,7 @@ def sppf(sd, p, x, k=5, train=False, fused=False):
     return conv_bn_act(sd, p + "cv2.", torch.cat(y, 1), train=train, fused=fused)
 
 
-def attention(sd, p, x, num_heads, attn_ratio=0.5, train=False, fused=False):
+def attention(sd, p, x, num_heads, attn_ratio=0.5, train=False, fused=False, res=None):
     B, C, H, W = x.shape
     N = H * W
     hd = C // num_heads
@@ -221,16 +297,15 @@ def attention(sd, p, x, num_heads, attn_ratio=0.5, train=False, fused=False):
     qkv = conv_bn_act(sd, p + "qkv.", x, act=False, train=train, fused=fused)
     q, k, v = qkv.view(B, num_heads, 2 * kd + hd, N).split([kd, kd, hd], dim=2)
     attn = ((q.transpose(-2, -1) @ k) * kd ** -0.5).softmax(dim=-1)
-    o = (v @ attn.transpose(-2, -1)).view(B, C, H, W)
-    o = o + conv_bn_act(sd, p + "pe.", v.reshape(B, C, H, W), 3, 1, g=C, act=False, train=train, fused=fused)
-    return conv_bn_act(sd, p + "proj.", o, act=False, train=train, fused=fused)
+    o = _st((v @ _op(attn).transpose(-2, -1)).view(B, C, H, W))      # probabilities enter the second product as 16-bit operands
+    o = conv_bn_act(sd, p + "pe.", v.reshape(B, C, H, W), 3, 1, g=C, act=False, train=train, fused=fused, res=o)
+    return conv_bn_act(sd, p + "proj.", o, act=False, train=train, fused=fused, res=res)
 
 
 def psablock(sd, p, x, num_heads, train=False, fused=False):
-    x = x + attention(sd, p + "attn.", x, num_heads, 0.5, train, fused)
+    x = attention(sd, p + "attn.", x, num_heads, 0.5, train, fused, res=x)
     y = conv_bn_act(sd, p + "ffn.0.", x, train=train, fused=fused)
-    y = conv_bn_act(sd, p + "ffn.1.", y, act=False, train=train, fused=fused)
-    return x + y
+    return conv_bn_act(sd, p + "ffn.1.", y, act=False, train=train, fused=fused, res=x)
 
 
 def c2psa(sd, p, x, n=1, e=0.5, train=False, fused=False):
@@ -274,13 +349,13 @@ def detect_head(sd, p, feats, nc, train=False, fused=False):
         c = x.shape[1]
         b = conv_bn_act(sd, f"{p}cv2.{i}.0.", x, 3, train=train, fused=fused)
         b = conv_bn_act(sd, f"{p}cv2.{i}.1.", b, 3, train=train, fused=fused)
-        b = F.conv2d(b, sd[f"{p}cv2.{i}.2.weight"], sd[f"{p}cv2.{i}.2.bias"])
+        b = F.conv2d(b, _op(sd[f"{p}cv2.{i}.2.weight"]), sd[f"{p}cv2.{i}.2.bias"])        # f32 logits (no output rounding)
         c3 = sd[f"{p}cv3.{i}.0.1.conv.weight"].shape[0]
         s_ = conv_bn_act(sd, f"{p}cv3.{i}.0.0.", x, 3, g=c, train=train, fused=fused)
         s_ = conv_bn_act(sd, f"{p}cv3.{i}.0.1.", s_, 1, train=train, fused=fused)
         s_ = conv_bn_act(sd, f"{p}cv3.{i}.1.0.", s_, 3, g=c3, train=train, fused=fused)
         s_ = conv_bn_act(sd, f"{p}cv3.{i}.1.1.", s_, 1, train=train, fused=fused)
-        s_ = F.conv2d(s_, sd[f"{p}cv3.{i}.2.weight"], sd[f"{p}cv3.{i}.2.bias"])
+        s_ = F.conv2d(s_, _op(sd[f"{p}cv3.{i}.2.weight"]), sd[f"{p}cv3.{i}.2.bias"])
         outs.append(torch.cat((b, s_), 1))
     return outs
 
@@ -302,6 +377,7 @@ STRIDES = (8.0, 16.0, 32.0)
 def forward(sd, layers, x, train=False, fused=False):
     """BaseModel._predict_once over the resolved graph.  train -> 3 raw maps; eval -> (y, maps)."""
     saved = []
+    x = _st(x)                                     # the 16-bit stem reads the image in the compute dtype
     for L in layers:
         i, f, kind = L["i"], L["f"], L["kind"]
         p = f"model.{i}."

@@ -1,0 +1,101 @@
+"""Shared body of the f16 parity tests (tests/test_model_gpu.py, tests/test_fusion_gpu.py).
+
+What is compared: the HIP path in its f16 mode (the reference's AMP dtype, engine/trainer.py:378) against the oracle under
+``emulate_f16`` — the CPU restatement with the SAME rounding points (16-bit operands and stored activations / gradients,
+f32 accumulation), so the two differ by summation order only, not by the quantisation itself.
+
+Why the model state is "default initialisation + a few hundred f32 SGD steps on the device": at initialisation every anchor
+predicts the same box / class logits (Detect.bias_init), the task-aligned assigner's top-10 is a tie everywhere and flips
+wholesale on last-bit noise — two IDENTICAL f16 runs of the product then differ by 38 % in the gradient (tools/fp16_emu_check.py,
+r02).  A few optimizer steps break the ties; after that two identical runs agree to ~1e-3 and the comparison has power.
+The state is just an input: both sides evaluate the same function at it.
+
+Bars (north_star / VERDICT r01 #1): loss within 2e-3 (absolute bar); whole-gradient relative error within 1e-2, per-tensor
+median within 1e-2, every tensor within 2 % of its norm (+ a floor of 1e-4 of the largest tensor norm) — each of the three
+gradient bars PLUS three times the spread of three identical device runs of the same quantity (per tensor: at least the 90th percentile of all tensors' relative spreads): filters in front of a
+BatchNorm and biases feeding one have an exactly-zero or near-zero true gradient, what is measured there is 16-bit rounding
+noise on the device and in the emulation alike, and how chaotic the pre-trained state is varies from run to run.  Typical
+r02 numbers: yolo11n loss 2e-5, whole gradient 6e-3 (rerun 2.5e-3), median 6e-3; fusion variant 5e-6 / 1.4e-3 (2.2e-3) / 2.3e-3."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from oracle import loss_ref, yolo11_ref as R
+
+DEV = "cuda"
+
+
+def pretrained_state(cfg, nc, nb, sz, steps, seed=11):
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+    torch.manual_seed(seed)
+    m0 = DetectionModel(cfg, ch=3, nc=nc, verbose=False)
+    tr = DetectionTrainer(m0, batch_size=nb, device=DEV, overrides={"amp": False, "nbs": nb, "warmup_epochs": 0}, graphs=False)
+    g = torch.Generator().manual_seed(seed)
+    for _ in range(steps):
+        n = 3 * nb
+        b = {"img": torch.rand(nb, 3, sz, sz, generator=g).to(DEV), "batch_idx": torch.arange(nb).repeat_interleave(3).float().to(DEV),
+             "cls": torch.randint(0, nc, (n, 1), generator=g).float().to(DEV),
+             "bboxes": torch.cat((0.25 + 0.5 * torch.rand(n, 2, generator=g), 0.1 + 0.4 * torch.rand(n, 2, generator=g)), 1).to(DEV)}
+        tr.train_step(b)
+    return {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+
+
+def run_f16_parity(cfg, layers, nc, nb=16, sz=256, steps=200, loss_scale=64.0):
+    from sy11.nn.tasks import DetectionModel
+    sd = pretrained_state(cfg, nc, nb, sz, steps)
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(nb, 3, sz, sz, generator=g)
+    n = 2 * nb
+    batch = {"img": img, "batch_idx": torch.arange(nb).repeat_interleave(2).float(), "cls": torch.randint(0, nc, (n, 1), generator=g).float(),
+             "bboxes": torch.cat((0.3 + 0.4 * torch.rand(n, 2, generator=g), 0.15 + 0.4 * torch.rand(n, 2, generator=g)), 1)}
+
+    def device_run():
+        m = DetectionModel(cfg, ch=3, nc=nc, verbose=False)
+        m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+        m.load_state_dict(sd)
+        m._sy11_dtype = torch.float16
+        m = m.to(DEV).train()
+        loss, items = m({k: v.to(DEV) for k, v in batch.items()})
+        (loss * loss_scale).backward()                      # what GradScaler does: 16-bit gradients need the head room
+        return loss.item(), {k: p.grad.float().cpu() / loss_scale for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k, v in osd.items():
+        if v.dtype.is_floating_point and "running" not in k and ".dfl." not in k:
+            v.requires_grad_(True)
+    with R.emulate_f16():
+        maps = R.forward(osd, layers, img, train=True)
+    oloss, _ = loss_ref.detection_loss(maps, batch, nc=nc)
+    (oloss * loss_scale).backward()
+    og = {k: v.grad / loss_scale for k, v in osd.items() if v.requires_grad and v.grad is not None}
+    (l1, g1), (l2, g2), (l3, g3) = device_run(), device_run(), device_run()
+
+    assert abs(l1 - oloss.item()) <= 2e-3 * abs(oloss.item()), (l1, oloss.item())
+    keys = [k for k in g1 if k in og]
+    assert len(keys) >= 0.95 * len(og)
+    fa, fb = torch.cat([g1[k].flatten() for k in keys]), torch.cat([og[k].flatten() for k in keys])
+    whole = (fa - fb).norm().item() / fb.norm().item()
+    cos = torch.dot(fa, fb).item() / (fa.norm().item() * fb.norm().item())
+    fc = torch.cat([g2[k].flatten() for k in keys])
+    whole_noise = (fa - fc).norm().item() / fc.norm().item()      # two identical device runs
+    print(f"f16 parity {cfg}: loss rel {abs(l1 - oloss.item()) / abs(oloss.item()):.2e}, whole gradient {whole:.3e} (device rerun {whole_noise:.3e}), cosine {cos:.6f}")
+    assert whole <= 1e-2 + 3.0 * whole_noise and cos >= 0.9995, (whole, whole_noise, cos)
+    gmax = max(og[k].norm().item() for k in keys)
+    rel, rel_noise, dist, noise_abs = [], [], {}, {}
+    for k in keys:
+        dist[k] = (g1[k] - og[k]).norm().item()
+        noise_abs[k] = max((g1[k] - g2[k]).norm().item(), (g1[k] - g3[k]).norm().item(), (g2[k] - g3[k]).norm().item())
+        rel.append(dist[k] / (og[k].norm().item() + 1e-4 * gmax))
+        rel_noise.append(noise_abs[k] / (og[k].norm().item() + 1e-4 * gmax))
+    # a tensor's own three-run spread is a 3-sample estimate (it can be small by chance on one of ~300 tensors): never take
+    # the noise scale below the 90th percentile of the relative spreads of all tensors
+    q90 = float(np.quantile(rel_noise, 0.9))
+    bad = [(k, dist[k], og[k].norm().item(), noise_abs[k]) for k in keys
+           if dist[k] > 0.02 * og[k].norm().item() + 3.0 * max(noise_abs[k], q90 * og[k].norm().item()) + 1e-4 * gmax]
+    assert not bad, (q90, bad[:8])
+    # how chaotic the trained state is varies from run to run (the pre-training itself uses f32 atomics): every bar is
+    # "2e-3 / 1e-2 / 2 % beyond what two identical device runs differ by"
+    assert float(np.median(rel)) <= 1e-2 + 3.0 * float(np.median(rel_noise)), (float(np.median(rel)), float(np.median(rel_noise)))
+    return {"loss_rel": abs(l1 - oloss.item()) / abs(oloss.item()), "whole": whole, "cos": cos, "median": float(np.median(rel)), "max": max(rel)}

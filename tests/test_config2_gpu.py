@@ -1,0 +1,82 @@
+"""GPU: BASELINE configs[2] as a whole — YOLOv11-s train fwd+bwd at bs 64 / 640x640 FROM synthetic IQ through the HIP STFT
+producer into the captured training graph's static input (the path bench.py times; r01 only tested its pieces).
+
+Checks: (1) what the producer wrote into the graph's static input equals the oracle's spectrogram image on 2 of the 64
+samples (2e-3, the STFT bar); (2) the loss of the IQ-fed trainer equals the loss of a second trainer, same weights, fed that
+image tensor directly (lr 0 keeps the weights fixed); (3) the aliasing survives graph replay: three replays on NEW IQ change
+the loss, and the new loss again equals the image-fed trainer's loss on the new image."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle import stft_ref as S, yolo11_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B = 64
+
+
+def labels(seed):
+    g = torch.Generator().manual_seed(seed)
+    n = 3 * B
+    return {"batch_idx": torch.arange(B).repeat_interleave(3).float().to(DEV), "cls": torch.randint(0, 80, (n, 1), generator=g).float().to(DEV),
+            "bboxes": torch.cat((0.25 + 0.5 * torch.rand(n, 2, generator=g), 0.05 + 0.3 * torch.rand(n, 2, generator=g)), 1).to(DEV)}
+
+
+def make_trainer(sd, producer):
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+    m = DetectionModel("yolo11s.yaml", nc=80, verbose=False)
+    m.load_state_dict(sd)
+    # lr 0, no decay, no warm-up: the weights stay what they are, so losses of different trainers / steps are comparable
+    return DetectionTrainer(m, batch_size=B, device=DEV, producer=producer, graphs=True,
+                            overrides={"amp": True, "lr0": 0.0, "weight_decay": 0.0, "warmup_epochs": 0.0})
+
+
+def test_iq_to_graph_replayed_train_step_bs64_640():
+    from sy11.data.spectrogram import SpectrogramProducer
+    from sy11.engine import graph_static_input
+    from sy11.nn.tasks import DetectionModel
+    torch.manual_seed(0)
+    # weights: initialisation + 150 f32 SGD steps at 16x3x256x256 (tests/_f16_parity.py): at initialisation every anchor predicts
+    # its bias whatever the image shows, and "the replay computed on the new image" would show nowhere in the loss
+    from tests._f16_parity import pretrained_state
+    sd = pretrained_state("yolo11s.yaml", 80, nb=16, sz=256, steps=150)
+    prod = SpectrogramProducer(DEV)
+    t_iq, t_img = make_trainer(sd, prod), make_trainer(sd, None)
+    lab = labels(1)
+    iq_a = S.synthetic_iq(B, seed=5)
+    iq_b = S.synthetic_iq(B, seed=9)
+    assert iq_a.shape == (B, S.N_SAMPLES) and iq_a.dtype == torch.complex64
+    iq_a_d, iq_b_d = iq_a.to(DEV), iq_b.to(DEV)
+
+    losses = [float(t_iq.train_step({"iq": iq_a_d, **lab})[0]) for _ in range(4)]      # 2 eager steps, capture, 1 replay
+    cfg = t_iq.model.__dict__["_sy11_graph_cfg"]
+    assert len(cfg["entries"]) == 1 and cfg["last_train_entry"] is not None           # the last step WAS a replay
+    static = graph_static_input(t_iq.model, (B, 3, S.N_MEL, S.N_FRAMES))
+    assert static is not None
+    b = t_iq.preprocess_batch({"iq": iq_a_d, **lab})
+    assert b["img"].data_ptr() == static.data_ptr()                                   # the producer writes the static input itself
+    # (1) producer output inside the static input vs the oracle image
+    pick = [5, 40]
+    ref_img = S.spectrogram_image(iq_a[pick])
+    got = static[pick].float().cpu()
+    assert got.shape == ref_img.shape == (2, 3, S.N_MEL, S.N_FRAMES)
+    assert (got - ref_img).abs().max().item() < 2e-3
+    # (2) same weights, image fed directly
+    img_a = static.clone()
+    ref_losses = [float(t_img.train_step({"img": img_a, **lab})[0]) for _ in range(4)]
+    assert abs(losses[-1] - ref_losses[-1]) <= 2e-3 * abs(ref_losses[-1]), (losses, ref_losses)
+    assert max(losses) - min(losses) <= 2e-3 * abs(losses[-1]), losses               # lr 0: eager == captured == replayed
+    # (3) three replays on new IQ
+    new = [float(t_iq.train_step({"iq": iq_b_d, **lab})[0]) for _ in range(3)]
+    assert static.data_ptr() == graph_static_input(t_iq.model, (B, 3, S.N_MEL, S.N_FRAMES)).data_ptr()
+    assert (static - img_a).abs().mean().item() > 1e-2                                # a different image is in the static input ...
+    spread = max(max(losses) - min(losses), max(new) - min(new))
+    assert abs(new[-1] - losses[-1]) > 5.0 * spread + 1e-4 * abs(losses[-1]), (new, losses)   # ... and the replay computed on it
+    ref_b = S.spectrogram_image(iq_b[pick])
+    assert (static[pick].float().cpu() - ref_b).abs().max().item() < 2e-3
+    ref_new = float(t_img.train_step({"img": static.clone(), **lab})[0])
+    assert abs(new[-1] - ref_new) <= 2e-3 * abs(ref_new), (new, ref_new)
+    assert max(new) - min(new) <= 2e-3 * abs(new[-1]), new

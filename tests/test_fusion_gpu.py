@@ -120,20 +120,12 @@ def test_fusion_model_train_step_matches_reference_fp32():
     check(gold, "e2e.eval.y", y, rtol=1e-3, atol=1e-4)
 
 
-def test_fusion_model_fp16_loss_vs_oracle():
-    """The AMP-dtype path on a bigger batch (train-mode BN needs samples): loss within 3e-2 of the CPU oracle."""
-    torch.manual_seed(5)
-    m = fusion_model(torch.float16).train()
-    img = torch.rand(8, 3, 128, 128)
-    batch = {"img": img.to(DEV), "batch_idx": torch.tensor([0., 3., 7.]).to(DEV), "cls": torch.tensor([[1.], [0.], [1.]]).to(DEV),
-             "bboxes": torch.tensor([[0.4, 0.4, 0.5, 0.4], [0.6, 0.65, 0.3, 0.5], [0.5, 0.5, 0.7, 0.6]]).to(DEV)}
-    loss, _ = m(batch)
-    loss.backward()
-    layers = R.resolve_graph("s", nc=2, graph=R.GRAPH_FUSION)
-    maps = R.forward(fusion_sd(), layers, img, train=True)
-    oloss, _ = loss_ref.detection_loss(maps, {k: v.cpu() for k, v in batch.items()}, nc=2)
-    assert abs(loss.item() - oloss.item()) <= 3e-2 * abs(oloss.item()), (loss.item(), oloss.item())
-    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+def test_fusion_model_f16_path_matches_f16_emulating_oracle():
+    """configs[4]'s dtype on configs[4]'s model: yolo11s_fusion_sand3_new (nc = 2) in f16 against the oracle under emulate_f16
+    — loss 2e-3, whole gradient 1e-2, per tensor 2 % beyond the device's own run-to-run deviation (tests/_f16_parity.py)."""
+    from tests._f16_parity import run_f16_parity
+    r = run_f16_parity("yolo11s_fusion_sand3_new.yaml", R.resolve_graph("s", nc=2, graph=R.GRAPH_FUSION), nc=2, nb=8, sz=192, steps=150)
+    print("f16 parity fusion variant:", r)
 
 
 def test_fusion_model_trainer_graph_replay_matches_eager():

@@ -169,19 +169,18 @@ def test_tiny_model_eval_and_fused_match_reference_fp32():
         check(gold, "eval_fused.y", yf, rtol=2e-3, atol=2e-4)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.float16, 3e-2)])
-def test_model_vs_oracle_fresh_inputs_yolo11n(dtype, tol):
-    """Full-width yolo11n at 2x3x128x128 on seeded random inputs: device forward/loss/grads vs the oracle on CPU.
-    fp32: the north-star 1e-3.  fp16 (the reference AMP dtype; operands rounded, f32 accumulate): 3e-2 -- two identical fp16 runs already differ by 0.5 % on this random-weight model (atomic summation order amplified by BatchNorm)."""
+def test_model_vs_oracle_fresh_inputs_yolo11n():
+    """Full-width yolo11n at 2x3x128x128 on seeded random inputs: device forward / loss / gradients in fp32 vs the oracle on
+    CPU at the north-star 1e-3 (loss) and 1 % per tensor (median 2e-3)."""
     from sy11.nn.tasks import DetectionModel
     torch.manual_seed(3)
     m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
     m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
     sd = R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=1)
     m.load_state_dict(sd)
-    m._sy11_dtype = dtype
+    m._sy11_dtype = torch.float32
     m = m.to(DEV).train()
-    nb = 2 if dtype == torch.float32 else 8          # fp16: more BN samples so operand rounding is not amplified
+    nb = 2
     img = torch.rand(nb, 3, 128, 128)
     batch = {"img": img.to(DEV), "batch_idx": torch.tensor([0., 0., float(nb - 1)]).to(DEV),
              "cls": torch.tensor([[3.], [17.], [60.]]).to(DEV),
@@ -197,25 +196,31 @@ def test_model_vs_oracle_fresh_inputs_yolo11n(dtype, tol):
             osd[k] = osd[k].detach()
     maps = R.forward(osd, layers, img, train=True)
     oloss, oitems = loss_ref.detection_loss(maps, {k: v.cpu() for k, v in batch.items()}, nc=80)
-    assert abs(loss.item() - oloss.item()) <= tol * abs(oloss.item()), (loss.item(), oloss.item())
-    np.testing.assert_allclose(items.cpu().numpy(), oitems.numpy(), rtol=tol, atol=1e-5)
+    assert abs(loss.item() - oloss.item()) <= 1e-3 * abs(oloss.item()), (loss.item(), oloss.item())
+    np.testing.assert_allclose(items.cpu().numpy(), oitems.numpy(), rtol=1e-3, atol=1e-5)
     loss.backward()
     oloss.backward()
     params = dict(m.named_parameters())
     gmax = max(osd[k].grad.norm().item() for k in params if osd[k].grad is not None)
-    # fp16: 2 images x 4x4 P5 cells -> BatchNorm over 32 samples amplifies operand rounding; per-tensor bound 25 %,
-    # median 5 %.  fp32: 1 % per tensor.
-    gtol = 1e-2 if dtype == torch.float32 else 0.25
     bad, rels = [], []
     for k, p in params.items():
         if not p.requires_grad:
             continue
         d = (p.grad.cpu() - osd[k].grad).norm().item()
         rels.append(d / (osd[k].grad.norm().item() + 1e-4 * gmax))
-        if d > gtol * osd[k].grad.norm().item() + 1e-4 * gmax:
+        if d > 1e-2 * osd[k].grad.norm().item() + 1e-4 * gmax:
             bad.append((k, d, osd[k].grad.norm().item()))
     assert not bad, bad[:8]
-    assert float(np.median(rels)) <= (2e-3 if dtype == torch.float32 else 8e-2), float(np.median(rels))
+    assert float(np.median(rels)) <= 2e-3, float(np.median(rels))
+
+
+def test_f16_path_matches_f16_emulating_oracle_yolo11n():
+    """The dtype that is benchmarked.  yolo11n, 16x3x256x256, f16 operands / activations / gradients with f32 accumulation,
+    against the oracle under emulate_f16 (same rounding points): loss 2e-3, whole gradient 1e-2, per tensor 2 % beyond the
+    device's own run-to-run deviation.  See tests/_f16_parity.py for the model state and why."""
+    from tests._f16_parity import run_f16_parity
+    r = run_f16_parity("yolo11n.yaml", R.resolve_graph("n", nc=80), nc=80)
+    print("f16 parity yolo11n:", r)
 
 
 @pytest.mark.parametrize("scale,n_params", [("n", 2624080), ("s", 9458752), ("m", 20114688), ("l", 25372160), ("x", 56966176)])
