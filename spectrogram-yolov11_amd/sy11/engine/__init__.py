@@ -118,6 +118,7 @@ class Ctx:
         self.dtype = dtype
         self.device = device
         self.tape: List = []
+        self.marks = {}               # name -> tape length at a point of the forward pass ("bucket": first closure of the split layer)
         self.grads = grads
         # one memset for all the small f32 accumulators (BN statistics, backward sums) of a step instead of ~160 fills
         self.pool = torch.zeros(pool_hint, dtype=torch.float32, device=device) if pool_hint > 0 else None
@@ -193,6 +194,7 @@ class GradStore:
         self.params = list(order) if order is not None else [p for p in module.parameters() if p.requires_grad]
         self.flat = None
         self.views = {}
+        self.offsets = {}             # id(param) -> first element in ``flat``
         self.external_zero = False    # True: the owner (trainer) zeroes ``flat`` itself after each optimizer step
 
     def _build(self, device):
@@ -209,6 +211,7 @@ class GradStore:
             else:
                 v = seg.view(p.shape)
             self.views[id(p)] = v
+            self.offsets[id(p)] = off
             off += pad(n)
 
     def begin_backward(self, device):
@@ -300,8 +303,13 @@ class EngineFn(torch.autograd.Function):
             if gv.dtype != a.data.dtype or not gv.is_contiguous():
                 gv = gv.to(a.data.dtype).contiguous()
             a.set_grad(gv)
-        for bw in reversed(ec.tape):
-            bw()
+        hook = module_post_backward.get(id(ec.grads)) if ec.grads is not None else None
+        mark = ec.marks.get("bucket") if (hook is not None and getattr(hook, "staged", False)) else None
+        for idx in range(len(ec.tape) - 1, -1, -1):
+            ec.tape[idx]()
+            if idx == mark:                         # every closure of the layers >= the split layer has run: their parameter
+                ec.join_side()                      # gradients are final -> the data-parallel hook may start reducing them
+                hook(ec.grads, 0)
         ec.join_side()
         ec.tape.clear()
         ctx.module.__dict__["_sy11_pool_hint"] = ec.pool_need       # next step: one pooled allocation
@@ -312,13 +320,14 @@ class EngineFn(torch.autograd.Function):
                 gin.append(g.float() if g.dtype != torch.float32 else g)
             else:
                 gin.append(None)
-        hook = module_post_backward.get(id(ec.grads)) if ec.grads is not None else None
         if hook is not None:
-            hook(ec.grads)
+            hook(ec.grads, 1)
         return (None, None, None, None, None, *gin, *([None] * (ctx.n_t - ctx.n_in)))
 
 
-# GradStore id -> callable(GradStore): set by the data-parallel wrapper to all-reduce the flat gradient buffer
+# GradStore id -> callable(GradStore, stage): set by the data-parallel wrapper to all-reduce the flat gradient buffer.
+# stage 1 = the backward pass is complete; a hook with ``.staged = True`` is also called with stage 0 as soon as the
+# gradients of the layers >= the model's bucket layer are final (the reference's DDP buckets, engine/trainer.py:273).
 module_post_backward = {}
 
 # Only the capturing thread's calls can invalidate a capture: under the default "global" mode a helper thread of the process
@@ -362,15 +371,30 @@ class _Graphed:
             self.outs, _ = _flatten(out)
             self.static_out = [from_act(a) for a in self.outs]
             self.static_gout = [torch.zeros_like(a.data) for a in self.outs]      # NHWC, activation dtype
+            hook = module_post_backward.get(id(store))
+            mark = ec.marks.get("bucket") if (hook is not None and getattr(hook, "staged", False)) else None
+            if mark is not None and not (0 < mark < len(ec.tape)):
+                mark = None
             self.g_bwd = torch.cuda.CUDAGraph()
+            self.g_bwd2 = None                                      # second half of a bucketed backward (data parallel only)
             with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), stream=side, capture_error_mode=_CAPTURE_MODE):
                 for a, g in zip(self.outs, self.static_gout):
                     if a.data.dim() == 4:
                         a.set_grad(g)
-                for bw in reversed(ec.tape):
-                    bw()
+                for idx in range(len(ec.tape) - 1, (mark if mark is not None else 0) - 1, -1):
+                    ec.tape[idx]()
                 ec.join_side()                                      # the wgrad branch joins inside the captured graph
-                self.static_gin = [a.grad_read().permute(0, 3, 1, 2) if a.req else None for a in acts]
+                if mark is None:
+                    self.static_gin = [a.grad_read().permute(0, 3, 1, 2) if a.req else None for a in acts]
+            if mark is not None:
+                # the layers below the split: a graph of their own, so that the first bucket's all-reduce can be issued
+                # between the two replays and run beside this one
+                self.g_bwd2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_bwd2, pool=self.g_fwd.pool(), stream=side, capture_error_mode=_CAPTURE_MODE):
+                    for idx in range(mark - 1, -1, -1):
+                        ec.tape[idx]()
+                    ec.join_side()
+                    self.static_gin = [a.grad_read().permute(0, 3, 1, 2) if a.req else None for a in acts]
             ec.tape.clear()
         torch.cuda.current_stream(dev).wait_stream(side)
 
@@ -427,11 +451,15 @@ class GraphFn(torch.autograd.Function):
         for dst, g in zip(e.static_gout, gouts):
             if g is not None and dst.dim() == 4 and g.data_ptr() != dst.data_ptr():      # the criterion may have written in place
                 dst.copy_(g.permute(0, 2, 3, 1))
-        e.g_bwd.replay()
-        gin = [(g.float() if (req and g is not None) else None) for g, req in zip(e.static_gin, ctx.in_req)]
         hook = module_post_backward.get(id(e.store))
+        e.g_bwd.replay()
+        if e.g_bwd2 is not None:
+            if hook is not None:
+                hook(e.store, 0)                                    # layers >= the split are done: reduce them beside the rest
+            e.g_bwd2.replay()
+        gin = [(g.float() if (req and g is not None) else None) for g, req in zip(e.static_gin, ctx.in_req)]
         if hook is not None:
-            hook(e.store)
+            hook(e.store, 1)
         return (None, None, *gin, *([None] * (ctx.n_t - ctx.n_in)))
 
 

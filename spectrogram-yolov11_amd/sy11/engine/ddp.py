@@ -38,20 +38,147 @@ def allreduce_flat(flat: torch.Tensor, group=None):
     return flat
 
 
-def attach(model: torch.nn.Module, group=None):
-    """Make every engine backward of ``model`` end with the gradient all-reduce (no-op for world_size 1)."""
+BUCKET_LAYER = 5      # layers >= 5 of the yolo11 graph hold > 99 % of the parameters; layers 0-4 (320^2 ... 80^2 maps) a third of the backward time
+
+
+class _StagedAllReduce:
+    """The gradient exchange of one model as two buckets over the flat gradient buffer (the reference's DDP buckets,
+    engine/trainer.py:273, re-thought for one flat buffer):
+
+      stage 0  fires when the backward pass has finished every layer >= ``bucket_layer``: their parameters' ranges of the flat
+               buffer (a few contiguous runs: the tail of each optimizer group) are all-reduced ASYNCHRONOUSLY — RCCL runs them
+               on its own stream beside the backward of the high-resolution layers that is still to come;
+      stage 1  fires at the end of backward: the remaining few small runs are packed into one staging tensor, reduced with
+               ONE call (latency bound, ~tens of KB), unpacked, and the stage-0 handles are waited for (stream-side waits).
+
+    Without a stage-0 call (module without a bucket mark, accumulation window still open, eager sub-module) stage 1 reduces the
+    whole flat buffer with one call — the r01 behaviour.  SUM semantics: DDP's mean x the reference's `loss *= world_size`."""
+
+    staged = True
+
+    def __init__(self, model, store, group=None, bucket_layer=BUCKET_LAYER):
+        self.model, self.store, self.group, self.bucket_layer = model, store, group, bucket_layer
+        self.late = self.early = None
+        self.works = []
+        self.stage0_done = False
+        self.staging = None
+
+    def _ranges(self):
+        """(late, early) lists of [start, end) element ranges of store.flat, merged over adjacent parameters."""
+        if self.late is not None:
+            return
+        names = {id(p): k for k, p in self.model.named_parameters()}
+
+        def layer_of(p):
+            parts = names.get(id(p), "").split(".")
+            return int(parts[1]) if len(parts) > 2 and parts[0] == "model" and parts[1].isdigit() else 1 << 30
+        late, early = [], []
+        pad = lambda n: (n + 7) // 8 * 8                         # noqa: E731  (the GradStore / FlatState padding rule)
+        for p in self.store.params:
+            a = self.store.offsets[id(p)]
+            b = a + pad(p.numel())
+            dst = late if layer_of(p) >= self.bucket_layer else early
+            if dst and dst[-1][1] == a:
+                dst[-1][1] = b
+            else:
+                dst.append([a, b])
+        self.late, self.early = late, early
+
+    def __call__(self, s, stage):
+        if getattr(s, "defer_allreduce", False):
+            return
+        if stage == 0:
+            if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+                return
+            self._ranges()
+            if not self.late or not self.early:
+                return
+            self.works = [dist.all_reduce(s.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a, b in self.late]
+            self.stage0_done = True
+            return
+        if not self.stage0_done:                                  # nothing was started early: the whole buffer, one call
+            allreduce_flat(s.flat, self.group)
+            return
+        n = sum(b - a for a, b in self.early)
+        if self.staging is None or self.staging.numel() != n or self.staging.device != s.flat.device:
+            self.staging = torch.empty(n, dtype=s.flat.dtype, device=s.flat.device)
+        views = [s.flat[a:b] for a, b in self.early]
+        torch.cat(views, out=self.staging)
+        dist.all_reduce(self.staging, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for v in views:
+            v.copy_(self.staging[off:off + v.numel()])
+            off += v.numel()
+        for w in self.works:
+            w.wait()                                              # the current stream waits for the collective (no host block on RCCL)
+        self.works, self.stage0_done = [], False
+
+
+def attach(model: torch.nn.Module, group=None, bucket_layer=BUCKET_LAYER):
+    """Make every engine backward of ``model`` end with the gradient sum over ranks (no-op for world_size 1), the first
+    bucket overlapped with the rest of backward when the model is a layer graph (BaseModel)."""
     store = model.__dict__.get("_sy11_grads")
     if store is None:
         store = GradStore(model)
         model.__dict__["_sy11_grads"] = store
-    # gradient accumulation (accumulate > 1): the flat buffer sums the micro-steps, so it must be all-reduced ONCE, after the
+    # gradient accumulation (accumulate > 1): the flat buffer sums the micro-steps, so it must be reduced ONCE, after the
     # last backward of the window (the trainer raises ``store.defer_allreduce`` on the others) — reducing it after every
     # backward would re-sum the already reduced part.  SUM is linear: allreduce(sum_k g_k) == sum_k allreduce(g_k).
-    def hook(s):
-        if not getattr(s, "defer_allreduce", False):
-            allreduce_flat(s.flat, group)
-    module_post_backward[id(store)] = hook
+    layers = getattr(model, "model", None)
+    if bucket_layer and layers is not None and hasattr(layers, "__len__") and len(layers) > bucket_layer + 1:
+        model.__dict__["_sy11_bucket_layer"] = int(bucket_layer)
+    module_post_backward[id(store)] = _StagedAllReduce(model, store, group, bucket_layer)
     return model
+
+
+def share_tuner_picks(src: int = 0, group=None):
+    """Every rank runs the kernels rank ``src`` measured: the tile autotuner's pick tables go from ``src`` to everybody
+    (libsy11 sy11_tune_export / sy11_tune_import).  Collective: call on all ranks.  Returns the number of picks."""
+    from .. import _lib
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return len(_lib.tune_export()) // 16
+    box = [_lib.tune_export() if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src, group=group)
+    if dist.get_rank(group) != src:
+        _lib.load().sy11_tune_clear()
+        _lib.tune_import(box[0])
+    return len(box[0]) // 16
+
+
+def free_port() -> int:
+    """A free TCP port on the loopback interface (utils/dist.py:13-22 find_free_network_port)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch(script_args, nproc: int, env=None, timeout=None):
+    """One process per GPU on this node, as the reference's `generate_ddp_command` + subprocess.run do for
+    `YOLO(...).train(device=[0, 1, ...])` (utils/dist.py:25-66, engine/trainer.py:170-207): RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in the environment of ``nproc`` CHILD processes running ``python <script_args...>``.
+    Children are spawned, never exec'ed over this process, and the caller must not have initialised the GPU in a way the
+    children inherit (they are fresh interpreters).  Returns the list of exit codes; raises if any is non-zero."""
+    import subprocess
+    import sys
+    port = free_port()
+    base = dict(os.environ if env is None else env)
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(nproc), HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(nproc):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, *script_args], env=e))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait(timeout=timeout))
+    finally:
+        for p in procs:                                  # never leave ranks behind (exact PIDs, no pattern kills)
+            if p.poll() is None:
+                p.kill()
+    if any(codes):
+        raise RuntimeError(f"data-parallel launch failed: exit codes {codes}")
+    return codes
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):

@@ -7,6 +7,8 @@ the YAML's folder) and the keyword overrides that map onto this build's trainer 
 reference's ``Model`` offers (export, tune, track, benchmark, HUB, callbacks) is out of scope."""
 from __future__ import annotations
 
+import os
+
 import random
 from pathlib import Path
 from types import SimpleNamespace
@@ -119,6 +121,15 @@ class YOLO:
         from ..data.dataset import build_dataloader, build_yolo_dataset
         from . import ddp
         from .trainer import DetectionTrainer
+        devices = _device_list(overrides.pop("device", None))
+        if len(devices) > 1 and "RANK" not in os.environ:
+            # engine/trainer.py:170-207 + utils/dist.py:25-66: `device=[0, 1, ...]` outside a launcher -> one CHILD process per
+            # GPU runs this very call; the parent waits and then continues with best.pt, as the reference does
+            return self._train_ddp(devices, dict(data=data, epochs=epochs, batch=batch, imgsz=imgsz, workers=workers, seed=seed,
+                                                 save_dir=save_dir, close_mosaic=close_mosaic, patience=patience, lrf=lrf, cos_lr=cos_lr,
+                                                 resume=resume, val=val, **overrides))
+        if len(devices) == 1 and "RANK" not in os.environ:
+            self.device = torch.device("cuda", devices[0])
         unknown = set(overrides) - _TRAIN_KEYS - set(_hyp_defaults())
         if unknown:
             raise SyntaxError(f"unknown train arguments {sorted(unknown)} (sy11 carries {sorted(_TRAIN_KEYS | set(_hyp_defaults()))})")
@@ -153,6 +164,40 @@ class YOLO:
             self.model, self.ckpt = attempt_load_one_weight(str(best), device=dev)
         return hist
 
+    def _train_ddp(self, devices, kw):
+        """Spawn len(devices) ranks of `YOLO(<same model>).train(<same arguments>)` and wait (sy11.engine.ddp.launch)."""
+        import json
+        import tempfile
+        from . import ddp
+        from .. import _lib
+        if torch.cuda.is_initialized():
+            raise _lib.Sy11Error("train(device=[...]) starts one process per GPU and must do so before THIS process has touched "
+                                 "the GPU (construct YOLO(...) from a .yaml, or with device='cpu'); alternatively launch the "
+                                 "script with `python -m torch.distributed.run --nproc-per-node N`")
+        save_dir = str(kw.get("save_dir") or Path("runs") / "detect" / "train")
+        kw = {**kw, "save_dir": save_dir, "data": kw["data"] if isinstance(kw["data"], dict) else str(kw["data"])}
+        payload = {"pkg": str(Path(__file__).resolve().parents[2]), "model": self.model_name, "nc": getattr(self.model.model[-1], "nc", None),
+                   "kw": kw}
+        src = ("import json, sys\n"
+               f"P = json.loads({json.dumps(json.dumps(payload))})\n"
+               "sys.path.insert(0, P['pkg'])\n"
+               "from sy11.engine.model import YOLO\n"
+               "m = YOLO(P['model'], nc=P['nc']) if str(P['model']).endswith(('.yaml', '.yml')) else YOLO(P['model'])\n"
+               "m.train(**P['kw'])\n")
+        with tempfile.NamedTemporaryFile("w", suffix=".py", prefix="_sy11_ddp_", delete=False) as f:
+            f.write(src)
+        vis = ",".join(str(d) for d in devices)
+        try:
+            ddp.launch([f.name], len(devices), env={**os.environ, "HIP_VISIBLE_DEVICES": vis, "CUDA_VISIBLE_DEVICES": vis})
+        finally:
+            os.unlink(f.name)
+        best = Path(save_dir) / "best.pt"
+        last = Path(save_dir) / "last.pt"
+        ck = best if best.exists() else last
+        if ck.exists():
+            self.model, self.ckpt = attempt_load_one_weight(str(ck), device="cpu")
+        return ck
+
     def val(self, data=None, batch=32, imgsz=640, conf=0.001, iou=0.7, half=False, workers=8, **kw):
         """engine/model.py:623-670 -> DetectionValidator over the rect val loader."""
         from ..data.dataset import build_dataloader, build_yolo_dataset
@@ -184,6 +229,16 @@ class YOLO:
         return self.predictor(source, paths=paths)
 
     __call__ = predict
+
+
+def _device_list(device):
+    """`device=0`, `"0,1"`, `[0, 1]`, `"cuda:1"` -> list of GPU indices (utils/torch_utils.py select_device's parsing)."""
+    if device is None or device == "" or str(device) == "cpu":
+        return []
+    if isinstance(device, (list, tuple)):
+        return [int(d) for d in device]
+    txt = str(device).lower().replace("cuda:", "").replace("(", "").replace(")", "").replace("[", "").replace("]", "").replace(" ", "")
+    return [int(d) for d in txt.split(",") if d != ""]
 
 
 def _hyp_defaults():

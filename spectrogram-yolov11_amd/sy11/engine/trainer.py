@@ -69,6 +69,13 @@ class DetectionTrainer:
             self.ema = ModelEMA(self.model)
         if world_size > 1:
             ddp.attach(self.model)
+            # identical kernels on every rank: only rank 0 measures tile configurations (first eager step); its picks are
+            # broadcast after the eager warm-up steps, before the graphs are captured (train_step)
+            import os
+            self.rank = int(os.environ.get("RANK", "0"))
+            if self.device.type == "cuda" and self.rank != 0:
+                from .. import _lib
+                _lib.set_option("tune", 0)
         if graphs and not self.args.multi_scale:            # hipGraph replay of forward/backward after 2 eager steps (multi_scale draws a new
             # input size every step: one captured graph + activation pool per size would not pay, those runs stay eager)
             from . import enable_graphs
@@ -348,4 +355,6 @@ class DetectionTrainer:
             self.optimizer_step()
             self.last_opt_step = self.ni
         self.ni += 1
+        if self.world_size > 1 and self.ni <= 2 and self.device.type == "cuda":
+            ddp.share_tuner_picks()                              # collective; after each of the two eager steps that precede capture
         return loss.detach(), items

@@ -85,7 +85,10 @@ class BaseModel(nn.Module):
         widths = self.__dict__["_sy11_cat_width"]
         cats = {}
         y = []
+        split = self.__dict__.get("_sy11_bucket_layer")     # data parallel: gradients of layers >= split form the first bucket
         for m in self.model:
+            if m.i == split and ec.record:
+                ec.marks["bucket"] = len(ec.tape)
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
             out = None

@@ -140,7 +140,7 @@ DDP_SCRIPT = textwrap.dedent("""
     gs = m.__dict__["_sy11_grads"]
     gs.begin_backward(torch.device("cpu"))
     gs.flat.copy_(torch.arange(gs.flat.numel(), dtype=torch.float32) * (rank + 1))
-    module_post_backward[id(gs)](gs)                       # what EngineFn.backward calls at its end
+    module_post_backward[id(gs)](gs, 1)                    # what EngineFn.backward calls at its end
     expect = torch.arange(gs.flat.numel(), dtype=torch.float32) * 3   # rank0 (x1) + rank1 (x2): SUM, not mean
     assert torch.equal(gs.flat, expect), (gs.flat[:4], expect[:4])
     assert all(p.grad is not None and p.grad.data_ptr() == gs.views[id(p)].data_ptr() for p in m.parameters())
@@ -290,10 +290,10 @@ def test_allreduce_hook_defers_inside_an_accumulation_window():
         store.begin_backward(torch.device("cpu"))
         hook = module_post_backward[id(store)]
         store.defer_allreduce = True
-        hook(store)
+        hook(store, 1)
         assert calls == []
         store.defer_allreduce = False
-        hook(store)
+        hook(store, 1)
         assert calls == [store.flat.data_ptr()]
     finally:
         ddp.allreduce_flat = orig
@@ -334,3 +334,135 @@ def test_trainer_warmup_and_lr_schedule_follow_the_reference_rules():
     t2 = DetectionTrainer(DetectionModel("yolo11n.yaml", nc=80, verbose=False), batch_size=16, device="cpu",
                           overrides={"amp": False, "optimizer": "auto", "iterations": 300}, graphs=False)
     assert type(t2.optimizer).__name__ == "AdamW" and abs(t2.args.lr0 - round(0.002 * 5 / 84, 6)) < 1e-15 and t2.args.warmup_bias_lr == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- data parallel, world size 2 (gloo)
+DDP_TRAINER_SCRIPT = textwrap.dedent("""
+    import os, sys, math, torch, torch.distributed as dist
+    sys.path.insert(0, os.path.join(r"{root}", "spectrogram-yolov11_amd")); sys.path.insert(0, r"{root}")
+    from sy11.engine import ddp, module_post_backward
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+    rank, local, world = ddp.setup_process_group("gloo")
+    assert world == 2
+    torch.manual_seed(1 + rank)                                   # different initial weights per rank: the broadcast must fix that
+    m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
+    tr = DetectionTrainer(m, batch_size=16, device="cpu", overrides={{"amp": False, "nbs": 64, "warmup_epochs": 0}}, world_size=world, graphs=False)
+    assert tr.accumulate == 2 and tr.flat is not None           # nbs 64 / (16 x 2 ranks)
+    store = tr.grad_store
+    hook = module_post_backward[id(store)]
+    assert hook.staged and tr.model.__dict__["_sy11_bucket_layer"] == ddp.BUCKET_LAYER
+    w0 = tr.flat.flat.clone()
+    ref = w0.clone(); dist.broadcast(ref, 0)
+    assert torch.equal(w0, ref)                                   # rank-0 weights everywhere (DDP constructor semantics)
+    n = store.flat.numel()
+    base = torch.linspace(-1.0, 1.0, n)
+
+    class FakeBackward(torch.autograd.Function):                 # what EngineFn.backward does, minus the kernels: fill the flat
+        @staticmethod                                            # gradient views, call the hook at the bucket mark and at the end
+        def forward(ctx, w, step):
+            ctx.step = step
+            return w.sum() * 0.0 + 1.0
+        @staticmethod
+        def backward(ctx, g):
+            store.begin_backward(torch.device("cpu"))
+            store.flat.add_(base * (1.0 + rank) * (1.0 + 0.5 * ctx.step) * float(g))
+            hook(store, 0)
+            hook(store, 1)
+            return None, None
+
+    steps = []
+    tr.model.forward = lambda batch: (FakeBackward.apply(tr.flat_params[0], float(len(steps))), torch.zeros(3))
+    tr.preprocess_batch = lambda b: b
+    # expected: window of 2 micro-steps, gradient = SUM over ranks (x1 + x2) of the per-rank sums, then clip 10, SGD-nesterov
+    for it in range(4):
+        before = tr.flat.flat.clone()
+        tr.train_step({{}})
+        steps.append(it)
+        if it % 2 == 0:
+            assert torch.equal(tr.flat.flat, before) and store.flat.abs().sum() > 0          # window open: no step, no reduction
+            expect_local = base * (1.0 + rank) * (1.0 + 0.5 * it)
+            assert torch.allclose(store.flat, expect_local, atol=1e-6)                        # NOT reduced yet (deferred)
+        else:
+            assert not torch.equal(tr.flat.flat, before) and store.flat.abs().sum() == 0     # stepped, gradients cleared
+    # closed form of the two optimizer steps on every rank
+    w = w0.clone(); buf = torch.zeros_like(w); mom, lr = tr.args.momentum, tr.args.lr0
+    a, b_ = tr.flat.group_slices[0]
+    for win in range(2):
+        g = base * 3.0 * ((1.0 + 0.5 * (2 * win)) + (1.0 + 0.5 * (2 * win + 1)))             # ranks (1 + 2) x two micro-steps
+        # padding elements of the flat layout carry no parameter: the trainer's buffers keep them at zero only if grads there are
+        # ignored by nobody -- they are part of the clip norm exactly as in the product (same flat tensors)
+        coef = min(10.0 / (float(g.double().norm()) + 1e-6), 1.0)
+        g = g * coef
+        gd = g.clone(); gd[a:b_] += tr.optimizer.param_groups[1]["weight_decay"] * w[a:b_]
+        buf = gd.clone() if win == 0 else buf * mom + gd
+        w = w - lr * (gd + mom * buf)
+    assert torch.allclose(tr.flat.flat, w, rtol=1e-5, atol=1e-6), (tr.flat.flat - w).abs().max()
+    other = tr.flat.flat.clone(); dist.broadcast(other, 0)
+    assert torch.equal(other, tr.flat.flat)                       # ranks stay bit-identical
+    # bucket ranges partition the flat buffer
+    hook._ranges()
+    cover = torch.zeros(n)
+    for lo, hi in hook.late + hook.early:
+        cover[lo:hi] += 1
+    assert torch.equal(cover, torch.ones(n)) and len(hook.late) <= 3 and len(hook.early) <= 3
+    assert sum(hi - lo for lo, hi in hook.late) > 0.9 * n
+    # tuner picks: rank 0's table everywhere
+    from sy11 import _lib
+    import struct
+    if rank == 0:
+        _lib.tune_import(struct.pack("<Qii", 4242, 0, 3) + struct.pack("<Qii", 77, 1, 9))
+    else:
+        _lib.tune_import(struct.pack("<Qii", 1, 0, 1))
+    assert ddp.share_tuner_picks() == 2
+    assert sorted(_lib.tune_export()[i:i + 16] for i in (0, 16)) == sorted([struct.pack("<Qii", 4242, 0, 3), struct.pack("<Qii", 77, 1, 9)])
+    # early stopping: only rank 0 knows the fitness, everybody must leave fit() together (engine/trainer.py:456-461)
+    class Loader:
+        dataset = None
+        def __len__(self): return 1
+        def __iter__(self): return iter([{{}}])
+    import sy11.engine.validator as V
+    seen = []
+    def fake_validate(model, batches):
+        seen.append(1)
+        return {{"fitness": 0.5 - 0.1 * len(seen)}}              # gets worse every epoch
+    V.DetectionValidator = lambda *a, **k: fake_validate
+    hist = tr.fit(Loader(), epochs=6, val_batches=(lambda: [None]), save_dir=None, patience=2)
+    assert len(hist) == 3, len(hist)                              # epoch 0 sets best, epochs 1-2 are stale -> stop on BOTH ranks
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_ddp_real_trainer_step_accumulate_buckets_and_early_stop_gloo_world2(tmp_path):
+    """The N > 1 path on CPU: the REAL DetectionTrainer.train_step / optimizer_step / fit over flat buffers with an accumulation
+    window of 2, the two-bucket staged gradient sum over gloo, rank-0 weights and tuner picks everywhere, and the early-stop
+    broadcast — two ranks launched by sy11.engine.ddp.launch (the spawn-before-GPU-init launcher of train(device=[...]))."""
+    script = tmp_path / "ddp_trainer.py"
+    script.write_text(DDP_TRAINER_SCRIPT.format(root=str(ROOT)))
+    sys.path.insert(0, str(ROOT / "spectrogram-yolov11_amd"))
+    from sy11.engine import ddp
+    codes = ddp.launch([str(script)], 2, env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=300)
+    assert codes == [0, 0]
+
+
+def test_train_device_list_spawns_one_child_per_gpu(monkeypatch, tmp_path):
+    """YOLO(...).train(device=[0, 1]) outside a launcher: one child per GPU runs the same call (utils/dist.py:25-66); checked
+    here is the command the launcher receives (no GPUs in this container)."""
+    from sy11.engine import ddp
+    from sy11.engine.model import YOLO, _device_list
+    assert _device_list("0,1") == [0, 1] and _device_list([2, 3]) == [2, 3] and _device_list("cuda:1") == [1] and _device_list(None) == []
+    seen = {}
+
+    def fake_launch(args, nproc, env=None, timeout=None):
+        seen.update(args=list(args), nproc=nproc, env=env, src=open(args[0]).read())
+        return [0] * nproc
+    monkeypatch.setattr(ddp, "launch", fake_launch)
+    monkeypatch.delenv("RANK", raising=False)
+    y = YOLO("yolo11n.yaml", nc=3)
+    out = y.train(data={"train": "x", "val": "y", "names": {0: "a", 1: "b", 2: "c"}, "nc": 3}, epochs=2, batch=8, device=[0, 1], save_dir=str(tmp_path), lr0=0.02)
+    assert seen["nproc"] == 2 and seen["env"]["HIP_VISIBLE_DEVICES"] == "0,1"
+    assert "m.train(**P['kw'])" in seen["src"] and "yolo11n.yaml" in seen["src"] and '\\"lr0\\": 0.02' in seen["src"] and '\\"epochs\\": 2' in seen["src"]
+    assert not os.path.exists(seen["args"][0])                    # the temporary launcher file is removed
+    assert str(out).startswith(str(tmp_path))

@@ -159,3 +159,14 @@ def test_resume_restores_best_fitness_and_closes_mosaic_late():
     hist = t.fit(ld, epochs=10, val_batches=None, save_dir=None, close_mosaic=4, start_epoch=8)      # 8 >= 10 - 4: already past
     assert ld.dataset.closed == 1 and len(hist) == 2
     assert abs(t.best_fitness - 0.42) < 1e-12                   # no validation ran: the restored value stands
+
+
+@pytest.mark.parametrize("tag", ["sgd", "auto"])
+def test_flat_trainer_update_rule_matches_the_reference_trainer(tag):
+    """SURVEY §8(a) row 13 pinned to the reference: three optimizer steps (clip 10 -> fused SGD-nesterov / AdamW on the flat
+    buffers -> FlatEMA) on the MI355X against tests/golden/trainer.npz = the reference's build_optimizer + optimizer_step +
+    ModelEMA on the same model, gradients and BN-buffer updates (oracle/gen_golden_trainer.py): weights, EMA, momentum at 1e-5."""
+    from tests._trainer_parity import compare_with_reference, product_trainer, run_three_steps
+    tr = run_three_steps(product_trainer(tag, DEV, flat=True))
+    torch.cuda.synchronize()
+    compare_with_reference(tr, tag, rtol=2e-5)

@@ -1,13 +1,14 @@
 # SQ counters of one wgrad problem (tools/conv_micro.py ... wgrad): where do the wave cycles go?
 #   bash tools/pmc_wgrad.sh <tag> B H W C N k s [SY11_WGRAD_CFG]
 set -e
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"     # repo root: gpurun exports it; else derived from this script's path
 TAG=$1; shift
 ARGS="$1 $2 $3 $4 $5 $6 $7"
 export SY11_TUNE=0
 [ -n "$8" ] && export SY11_WGRAD_CFG=$8
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
-rm -rf $OUT; mkdir -p $OUT
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/a -o run -- python3 tools/conv_micro.py $ARGS ${MODE:-wgrad} 5 > $OUT/a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY --output-format csv -d $OUT/b -o run -- python3 tools/conv_micro.py $ARGS ${MODE:-wgrad} 5 > $OUT/b.log 2>&1

@@ -2,10 +2,11 @@
 #   bash tools/prof_bench.sh stats <tag>   kernel trace + per-kernel statistics (graph replay, the bench as the driver runs it)
 #   bash tools/prof_bench.sh pmc <tag>     HBM traffic counters, one pass per counter (eager launches: counters are per dispatch)
 set -e
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"     # repo root: gpurun exports it; else derived from this script's path
 MODE=$1; TAG=$2
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-rm -rf $OUT; mkdir -p $OUT
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd $GRAFT_REPO_ROOT
 if [ "$MODE" = stats ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline --no-fwd-leg > $OUT/bench.json 2> $OUT/bench.err
