@@ -6,6 +6,15 @@ A "step" = one pass of the hot path over one synthetic batch that is ALREADY RES
   -> backward (dgrad/wgrad/BN) -> [RCCL gradient sum when N > 1] -> unscale, clip 10, SGD-nesterov step, EMA.
 One process per GPU; for N > 1 launch with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the env).
 Rank 0 prints ONE JSON line.
+
+Besides the headline (`value`, configs[2]) the line carries, all measured after the timed region and never part of `value`:
+  roofline      the kernel family with the largest share of the step (HIP events around every C-ABI launch of one instrumented
+                step, issued behind a head-start delay so that the GPU never waits for the host between launches), its algorithmic
+                bytes / FLOPs, the HBM traffic of the same family from the rocprofv3 PMC passes (profiles/r02/traffic.json);
+  peaks         measured on this GPU in this run: pure-MFMA loop (sy11_peak_mfma_f16) and a 1 GiB device-to-device copy;
+  cpu_baseline  the oracle (CPU restatement of the reference path) on the host cores: 7 threads (the reference's default
+                min(8, ncpu - 1)) and all cores, eval forward and train step;
+  forward_only  configs[1]; extra: the f32 train line and configs[4]'s model (fusion variant, nc = 2) at the same batch / size.
 """
 from __future__ import annotations
 
@@ -26,8 +35,20 @@ import torch.distributed as dist  # noqa: E402
 
 FWD_GFLOP_PER_IMG = 21.467          # 88 Conv2d of yolo11s @ 640x640 (algorithmic, 2*MAC)
 TRAIN_GFLOP_PER_IMG = 64.40         # fwd + dgrad + wgrad (first layer has no dgrad)
+FUSION_FWD_GFLOP_PER_IMG = 18.892   # yolo11s_fusion_sand3_new, nc = 2
 PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0               # HBM3E spec peak (~6300 achievable), MI355X_MICROARCH.md
+PROFILE_DIR = ROOT / "profiles" / "r02"
+
+# kernel family -> the C-ABI entry points that launch it, and the kernel symbols a rocprofv3 trace shows for it
+FAMILIES = {
+    "conv fwd+dgrad (dense)": {"calls": ("sy11_conv2d_fwd", "sy11_conv2d_dgrad"), "symbols": ("igemm_kernel", "igemm1x1p_kernel")},
+    "conv wgrad (dense)": {"calls": ("sy11_conv2d_wgrad",), "symbols": ("wgrad16_kernel", "wgrad_kernel")},
+    "depthwise conv": {"calls": (), "symbols": ("dw3x3_kernel", "dwconv_")},
+    "batchnorm": {"calls": ("sy11_bn_act_fwd", "sy11_bn_act_bwd_reduce", "sy11_bn_act_bwd_apply", "sy11_bn_finalize"),
+                  "symbols": ("bn_act_fwd_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "bn_finalize_kernel")},
+    "stem": {"calls": ("sy11_stem_conv_fwd", "sy11_stem_conv_wgrad"), "symbols": ("stem_fwd_mma", "stem_wgrad_mma")},
+}
 
 
 def synthetic_iq(batch, n_samples, seed, device):
@@ -60,32 +81,139 @@ def synthetic_labels(batch, seed, device, nc=80):
             "bboxes": torch.cat((cxcy, wh), 1).to(device)}
 
 
-def cpu_baseline(batch=4, imgsz=640, iters=2):
-    """The oracle (CPU restatement of the reference path, plain PyTorch fp32) timed on this host's cores."""
+def host_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands one GPU's share of
+    the host — 16 CPUs — to a job while every core of the machine stays visible)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def cpu_baseline(batch=8, imgsz=640, leg_budget_s=22.0):
+    """SURVEY §8(d) / BASELINE.md §3: the oracle (plain PyTorch fp32 restatement of the reference path) on this host's cores, at
+    n = 7 threads (the reference's own default min(8, ncpu - 1), utils/__init__.py:44) and n = all usable cores; warm-up + up to 5
+    timed iterations each of (a) eval forward and (b) train fwd + loss + bwd, every leg bounded to ~20 s (>= 2 timed iterations).
+    A bounded sample of the bench workload: same model, size and inputs at batch 8 (a train iteration at batch 64 takes a minute)."""
     sys.path.insert(0, str(ROOT))
     from oracle import loss_ref, yolo11_ref as R
+    t_start = time.perf_counter()
     torch.manual_seed(0)
     layers = R.resolve_graph("s", nc=80)
     sd = R.seeded_state_dict(R.empty_state_dict(layers), seed=0)
-    for k, v in sd.items():
-        if v.dtype.is_floating_point and "running" not in k:
-            v.requires_grad_(True)
     img = torch.rand(batch, 3, imgsz, imgsz)
     lab = synthetic_labels(batch, 0, "cpu")
-    times = []
-    for it in range(iters + 1):
-        t0 = time.perf_counter()
-        maps = R.forward(sd, layers, img, train=True)
-        loss, _ = loss_ref.detection_loss(maps, lab, nc=80)
-        loss.backward()
-        for v in sd.values():
-            v.grad = None
-        if it:
-            times.append(time.perf_counter() - t0)
-    dt = sum(times) / len(times)
-    return {"value": round(batch / dt, 3), "unit": "spectrogram-images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} timed + 1 warm-up train fwd+loss+bwd iterations of yolo11s {imgsz}x{imgsz} at batch {batch} "
-                      f"(oracle/yolo11_ref.py + loss_ref.py, fp32, torch {torch.get_num_threads()} threads)"}
+    ncpu = host_cpus()
+    runs = []
+
+    def timed(fn, warm, iters, what):
+        t_leg = time.perf_counter()
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_leg > leg_budget_s and len(ts) >= 2:
+                break
+        print(f"[bench] cpu baseline: {what}: {len(ts)} iterations, {sum(ts) / len(ts):.2f} s each", file=sys.stderr, flush=True)
+        return sum(ts) / len(ts), len(ts)
+
+    for n in sorted({min(7, ncpu), ncpu}):
+        torch.set_num_threads(n)
+        esd = {k: v.clone() for k, v in sd.items()}
+
+        def fwd():
+            with torch.no_grad():
+                R.forward(esd, layers, img, train=False)
+        dt, it = timed(fwd, 1, 5, f"eval forward, {n} threads")
+        runs.append({"mode": "eval forward", "threads": n, "batch": batch, "iters": it, "img_s": round(batch / dt, 3),
+                     "gflops": round(batch / dt * FWD_GFLOP_PER_IMG, 1)})
+        tsd = {k: v.clone() for k, v in sd.items()}
+        for k, v in tsd.items():
+            if v.dtype.is_floating_point and "running" not in k:
+                v.requires_grad_(True)
+
+        def train():
+            maps = R.forward(tsd, layers, img, train=True)
+            loss, _ = loss_ref.detection_loss(maps, lab, nc=80)
+            loss.backward()
+            for v in tsd.values():
+                v.grad = None
+        dt, it = timed(train, 1, 5, f"train fwd+loss+bwd, {n} threads")
+        runs.append({"mode": "train fwd+loss+bwd", "threads": n, "batch": batch, "iters": it, "img_s": round(batch / dt, 3),
+                     "gflops": round(batch / dt * TRAIN_GFLOP_PER_IMG, 1)})
+    best = max((r for r in runs if r["mode"].startswith("train")), key=lambda r: r["img_s"])
+    return {"value": best["img_s"], "unit": "spectrogram-images/s", "cores": best["threads"], "kind": "port",
+            "sample": f"yolo11s {imgsz}x{imgsz} at batch {batch} (the bench workload at 1/8 of its batch): train fwd+loss+bwd, "
+                      f"{best['iters']} timed + 1 warm-up iterations, oracle/yolo11_ref.py + loss_ref.py, fp32, {best['threads']} torch threads",
+            "host_cpus": ncpu, "runs": runs, "wall_s": round(time.perf_counter() - t_start, 1)}
+
+
+def measured_peaks(dev):
+    """The roofs as THIS GPU delivers them: a pure-MFMA f16 loop and a large device-to-device copy."""
+    import ctypes as C
+
+    from sy11 import _lib
+    lib = _lib.load()
+    wgs, iters = 256 * 8, 4000
+    out = torch.empty(wgs * 4, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.sy11_peak_mfma_f16(wgs, 200, C.c_void_p(out.data_ptr()), st), "peak")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(lib.sy11_peak_mfma_f16(wgs, iters, C.c_void_p(out.data_ptr()), st), "peak")
+    e1.record()
+    torch.cuda.synchronize()
+    tf = wgs * 4 * iters * 8 * 32768 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)       # 1 GiB
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return {"mfma_f16_tflops": round(tf, 1), "mfma_f16_vs_datasheet": round(tf / PEAK_TFLOPS["f16"], 3),
+            "device_copy_GBps": round(gbs, 1), "device_copy_vs_datasheet": round(gbs / PEAK_HBM_GBS, 3),
+            "how": "sy11_peak_mfma_f16 (2048 workgroups x 4 waves x 32000 v_mfma_f32_32x32x16_f16, registers only); torch copy_ of 1 GiB (read + write bytes)"}
+
+
+def family_of(name, meta):
+    if name.startswith("sy11_conv2d") and meta and meta.get("groups", 1) > 1:
+        return "depthwise conv"          # depthwise / grouped calls run the direct kernels: kept out of the dense families
+    for fam, spec in FAMILIES.items():
+        if name in spec["calls"]:
+            return fam
+    return name
+
+
+def timed_steps(step, fence, steps, warmup):
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -96,12 +224,14 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--model", default="yolo11s.yaml")
+    ap.add_argument("--nc", type=int, default=80, help="classes of the Detect head (2 for the fusion variant of configs[4])")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--no-stft", action="store_true", help="feed resident (B,3,H,W) images instead of IQ")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fwd-leg", action="store_true", help="skip the forward-only (configs[1]) leg reported next to the headline")
+    ap.add_argument("--no-extras", action="store_true", help="skip the f32 train line and the configs[4] model line")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel individually instead of hipGraph replay")
     a = ap.parse_args()
 
@@ -120,15 +250,19 @@ def main():
     dev = torch.device("cuda", local)
     torch.manual_seed(0 + 1 + rank)                        # trainer.py:107 init_seeds(seed + 1 + RANK)
 
-    model = DetectionModel(a.model, nc=80, verbose=False)
-    producer = SpectrogramProducer(dev, n_frames=a.imgsz, n_mel=a.imgsz) if not a.no_stft else None
-    tr = DetectionTrainer(model, batch_size=a.batch, device=dev, overrides={"amp": a.dtype == "f16"}, world_size=world,
-                          producer=producer, graphs=not a.no_graphs)
-    labels = synthetic_labels(a.batch, 100 + rank, dev)
-    if producer is not None:
-        data = {"iq": synthetic_iq(a.batch, producer.n_samples, 1 + rank, dev)}
-    else:
-        data = {"img": torch.rand(a.batch, 3, a.imgsz, a.imgsz, device=dev)}
+    def make(model_yaml, nc, dtype, with_producer, ws=1):
+        model = DetectionModel(model_yaml, nc=nc, verbose=False)
+        producer = SpectrogramProducer(dev, n_frames=a.imgsz, n_mel=a.imgsz) if with_producer else None
+        tr = DetectionTrainer(model, batch_size=a.batch, device=dev, overrides={"amp": dtype == "f16"}, world_size=ws,
+                              producer=producer, graphs=not a.no_graphs)
+        labels = synthetic_labels(a.batch, 100 + rank, dev, nc=nc)
+        if producer is not None:
+            data = {"iq": synthetic_iq(a.batch, producer.n_samples, 1 + rank, dev)}
+        else:
+            data = {"img": torch.rand(a.batch, 3, a.imgsz, a.imgsz, device=dev)}
+        return tr, data, labels
+
+    tr, data, labels = make(a.model, a.nc, a.dtype, not a.no_stft, world)
 
     def step():
         batch = {**data, **labels}
@@ -144,20 +278,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = timed_steps(step, fence, a.steps, a.warmup)
+    if rank == 0:
+        print(f"[bench] headline: {a.steps} steps, {dt / a.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     ms = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
+    fwd_gflop = FUSION_FWD_GFLOP_PER_IMG if "fusion" in a.model else FWD_GFLOP_PER_IMG
+    train_gflop = 3 * fwd_gflop - 0.177 if "fusion" in a.model else TRAIN_GFLOP_PER_IMG
 
     fwd_only = None
     if rank == 0 and world == 1 and a.mode == "train" and not a.no_fwd_leg:
@@ -179,76 +310,92 @@ def main():
         fdt = (time.perf_counter() - t1) / a.steps
         fwd_only = {"workload": "configs[1]: YOLOv11-s forward only, bs=64, resident spectrogram tensors", "value": round(a.batch / fdt, 1),
                     "unit": "spectrogram-images/s", "ms_per_step": round(fdt * 1e3, 3),
-                    "conv_tflops": round(a.batch / fdt * FWD_GFLOP_PER_IMG / 1e3, 2),
-                    "conv_roofline_frac": round(a.batch / fdt * FWD_GFLOP_PER_IMG / 1e3 / PEAK_TFLOPS[a.dtype], 4)}
+                    "conv_tflops": round(a.batch / fdt * fwd_gflop / 1e3, 2),
+                    "conv_roofline_frac": round(a.batch / fdt * fwd_gflop / 1e3 / PEAK_TFLOPS[a.dtype], 4)}
 
     roof = None
     if world > 1 and not a.no_roofline:
         step()                                                  # every rank takes the extra step: its gradient all-reduce must be matched
     if rank == 0 and not a.no_roofline:
-        # one instrumented step: every C-ABI launch bracketed by events on the launch stream
+        # one instrumented step: every C-ABI launch bracketed by events on the launch stream.  The launches are issued behind a
+        # ~60 ms head-start delay on the same stream, so the GPU works through an already filled queue: an event pair then spans
+        # the kernel(s) of the call, not the host's launch latency (r01: eager event timing read 9.8 ms for a family that takes
+        # 8.8 ms under graph replay)
+        from sy11.engine import module_post_backward
         tr.model.__dict__.pop("_sy11_graph_cfg", None)          # per-launch events need individually launched kernels
+        store = tr.model.__dict__.get("_sy11_grads")
+        hook = module_post_backward.pop(id(store), None) if (store is not None and world > 1) else None   # the collective happened above
+        step()                                                  # eager once (allocator warm, no capture bookkeeping in the timed step)
+        torch.cuda.synchronize()
         _lib.PROFILE = []
-        if world == 1:
-            step()
-        else:                                                   # the collective already happened above: instrument forward+backward only
-            store = tr.model.__dict__.get("_sy11_grads")
-            from sy11.engine import module_post_backward
-            hook = module_post_backward.pop(id(store), None) if store is not None else None
-            step()
-            if hook is not None:
-                module_post_backward[id(store)] = hook
+        torch.cuda._sleep(int(0.06 * 2.0e9))
+        step()
         torch.cuda.synchronize()
         prof, _lib.PROFILE = _lib.PROFILE, None
+        if hook is not None:
+            module_post_backward[id(store)] = hook
         fam = {}
         for name, e0, e1, meta in prof:
-            f = fam.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
-            f["ms"] += e0.elapsed_time(e1)
+            f = fam.setdefault(family_of(name, meta), {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "by_call": {}})
+            t = e0.elapsed_time(e1)
+            f["ms"] += t
             f["n"] += 1
+            c = f["by_call"].setdefault(name, {"ms": 0.0, "n": 0, "bytes": 0.0, "flops": 0.0})
+            c["ms"] += t
+            c["n"] += 1
             if meta and (name.startswith("sy11_conv2d") or name.startswith("sy11_stem")):
-                f["flops"] += meta["flops"]
-                f["bytes"] += meta["bytes"]
+                for d in (f, c):
+                    d["flops"] += meta["flops"]
+                    d["bytes"] += meta["bytes"]
         dump = os.environ.get("SY11_DUMP_LAUNCHES")
         if dump:
             with open(dump, "w") as fh:
                 for name, e0, e1, meta in prof:
+                    isconv = name.startswith(("sy11_conv2d", "sy11_stem"))
                     fh.write(json.dumps({"name": name, "ms": round(e0.elapsed_time(e1), 4),
-                                         "gflop": round((meta or {}).get("flops", 0) / 1e9, 3) if name.startswith(("sy11_conv2d", "sy11_stem")) else 0,
-                                         "mbytes": round((meta or {}).get("bytes", 0) / 1e6, 3) if name.startswith(("sy11_conv2d", "sy11_stem")) else 0,
-                                         "desc": (meta or {}).get("desc") if name.startswith(("sy11_conv2d", "sy11_stem")) else None}) + "\n")
-        top = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        name, f = top
+                                         "gflop": round((meta or {}).get("flops", 0) / 1e9, 3) if isconv else 0,
+                                         "mbytes": round((meta or {}).get("bytes", 0) / 1e6, 3) if isconv else 0,
+                                         "desc": (meta or {}).get("desc") if isconv else None}) + "\n")
+        name, f = max(fam.items(), key=lambda kv: kv[1]["ms"])
         peak = PEAK_TFLOPS[a.dtype]
-        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
-        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process)
-        tj = ROOT / "profiles" / "r01" / "traffic.json"
-        if tj.exists():
-            fam_t = json.loads(tj.read_text()).get("families", {}).get(name)
-            if fam_t:
-                traffic = round(fam_t["bytes_per_launch"])
-        # which roof binds the family: its arithmetic intensity (algorithmic FLOPs / algorithmic bytes) against the ridge
-        # peak_flops / peak_bandwidth.  yolo11s' conv families sit at ~140 FLOP/B in f16, below the 312 FLOP/B ridge -> HBM.
         secs = f["ms"] * 1e-3
+        ach_tf = f["flops"] / secs / 1e12 if secs > 0 else 0.0
+        ach_gb = f["bytes"] / secs / 1e9 if secs > 0 else 0.0
         ai = f["flops"] / max(f["bytes"], 1.0)
-        if f["bytes"] > 0 and ai < peak * 1e12 / (PEAK_HBM_GBS * 1e9):
-            ach_b = f["bytes"] / secs / 1e9 if secs > 0 else 0.0
-            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach_b / PEAK_HBM_GBS, 4)}
-        else:
-            roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
-        roof.update({"traffic": traffic, "arithmetic_intensity_flop_per_byte": round(ai, 1),
-                     "mfma_tflops": round(ach, 2), "mfma_frac": round(ach / peak, 4),
-                "algorithmic_bytes_per_launch": round(f["bytes"] / max(f["n"], 1)), "launches": f["n"],
-                "avg_launch_ms": round(f["ms"] / max(f["n"], 1), 4),
-                "families_ms": {k: round(v["ms"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}})
+        # which roof binds the family: its arithmetic intensity (algorithmic FLOPs / algorithmic bytes) against the ridge
+        # peak_flops / peak_bandwidth.  yolo11s' conv families sit at ~150 FLOP/B in f16, below the 312 FLOP/B ridge -> HBM.
+        hbm_bound = f["bytes"] > 0 and ai < peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+        traffic = None
+        tj = PROFILE_DIR / "traffic.json"
+        if tj.exists():                                          # HBM bytes of the same family from the rocprofv3 PMC passes
+            ft = json.loads(tj.read_text()).get("families", {}).get(name)
+            if ft:
+                traffic = {"bytes_per_step": round(ft["GB_per_step"] * 1e9), "kernel_launches_per_step": ft["launches_per_step"],
+                           "bytes_per_kernel_launch": round(ft["GB_per_step"] * 1e9 / max(ft["launches_per_step"], 1)),
+                           "vs_algorithmic": round(ft["GB_per_step"] * 1e9 / max(f["bytes"], 1.0), 3),
+                           "source": "profiles/r02/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections)"}
+        roof = {"kernel": name, "kernel_symbols": list(FAMILIES.get(name, {}).get("symbols", ())),
+                "bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(ach_gb, 1) if hbm_bound else round(ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round((ach_gb / PEAK_HBM_GBS) if hbm_bound else (ach_tf / peak), 4),
+                "traffic": traffic["bytes_per_step"] if traffic else None, "traffic_detail": traffic,
+                "per": "training step (all launches of the family in one step; `achieved` = algorithmic bytes of those launches / their summed duration)",
+                "arithmetic_intensity_flop_per_byte": round(ai, 1), "mfma_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak, 4),
+                "family_ms_per_step": round(f["ms"], 3), "c_abi_calls_per_step": f["n"],
+                "algorithmic_bytes_per_step": round(f["bytes"]), "algorithmic_gflop_per_step": round(f["flops"] / 1e9, 1),
+                "avg_call_ms": round(f["ms"] / max(f["n"], 1), 4),
+                "by_call": {k: {"ms": round(v["ms"], 3), "calls": v["n"], "algorithmic_GB": round(v["bytes"] / 1e9, 3),
+                                "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
+                            for k, v in f["by_call"].items()},
+                "families_ms": {k: round(v["ms"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+                "timing": "HIP events around each C-ABI call of one eager step issued behind a 60 ms head-start delay on the launch stream"}
 
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline()
+    peaks = measured_peaks(dev) if (rank == 0 and not a.no_roofline) else None
 
     if fwd_only is not None:
         # the deployed forward: BatchNorm folded into the convs (model.fuse()), eval mode, Detect decode included.  Last thing
-        # this process does with the model (fusing is destructive); reported inside `forward_only`, never part of `value`.
+        # this process does with the headline model (fusing is destructive); reported inside `forward_only`, never part of `value`.
         from sy11.engine import enable_graphs
         m = tr.model
         enable_graphs(m)                                        # fresh entries: the eval forward captures its own graph
@@ -267,11 +414,33 @@ def main():
         torch.cuda.synchronize()
         pdt = (time.perf_counter() - t2) / a.steps
         fwd_only["fused_eval"] = {"workload": "model.fuse() + eval forward incl. Detect decode (predictor path), bs=64", "value": round(a.batch / pdt, 1),
-                                  "ms_per_step": round(pdt * 1e3, 3), "conv_tflops": round(a.batch / pdt * FWD_GFLOP_PER_IMG / 1e3, 2),
-                                  "conv_roofline_frac": round(a.batch / pdt * FWD_GFLOP_PER_IMG / 1e3 / PEAK_TFLOPS[a.dtype], 4)}
+                                  "ms_per_step": round(pdt * 1e3, 3), "conv_tflops": round(a.batch / pdt * fwd_gflop / 1e3, 2),
+                                  "conv_roofline_frac": round(a.batch / pdt * fwd_gflop / 1e3 / PEAK_TFLOPS[a.dtype], 4)}
+
+    extra = None
+    if rank == 0 and world == 1 and a.mode == "train" and not a.no_extras and a.model == "yolo11s.yaml":
+        del tr
+        torch.cuda.empty_cache()
+        extra = {}
+        for key, (yaml_, nc, dtype, what, gf) in {
+                "f32_train": ("yolo11s.yaml", 80, "f32", "the headline workload with exact-f32 MFMA and no AMP (the dtype of the 1e-3 parity bar)", TRAIN_GFLOP_PER_IMG),
+                "configs4_model": ("yolo11s_fusion_sand3_new.yaml", 2, "f16", "configs[4]'s model (Spectrogram-YOLOv11, 6 824 734 parameters, nc = 2), f16 train step on one GPU",
+                                   3 * FUSION_FWD_GFLOP_PER_IMG - 0.177)}.items():
+            t2_, d2, l2 = make(yaml_, nc, dtype, True)
+            k = max(a.steps // 3, 5)
+            edt = timed_steps(lambda: t2_.train_step({**d2, **l2}), torch.cuda.synchronize, k, 4)
+            print(f"[bench] extra {key}: {edt / k * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
+            extra[key] = {"workload": what, "value": round(a.batch * k / edt, 1), "unit": "spectrogram-images/s", "ms_per_step": round(edt / k * 1e3, 3),
+                          "steps": k, "dtype": dtype, "conv_tflops": round(a.batch * k / edt * gf / 1e3, 2)}
+            del t2_, d2, l2
+            torch.cuda.empty_cache()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
 
     if rank == 0:
-        gflop = TRAIN_GFLOP_PER_IMG if a.mode == "train" else FWD_GFLOP_PER_IMG
+        gflop = train_gflop if a.mode == "train" else fwd_gflop
         out = {
             "metric": "spectrogram-images/sec (train fwd+bwd) YOLOv11-s 640², bs=64, 1/2/4/8 GPU" if a.mode == "train"
             else "spectrogram-images/sec (forward only) YOLOv11-s 640², bs=64",
@@ -283,10 +452,10 @@ def main():
                                     "configs[1]: YOLOv11-s forward" if a.mode == "fwd" else
                                     "YOLOv11-s train fwd+bwd from resident spectrogram tensors"),
                        "model": a.model, "imgsz": a.imgsz, "batch_per_gpu": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "weights": "random-init", "nc": 80},
+                       "parallelism": f"dp{world}", "weights": "random-init", "nc": a.nc},
             "conv_tflops": round(value * gflop / 1e3, 2),
             "conv_roofline_frac": round(value * gflop / 1e3 / PEAK_TFLOPS[a.dtype], 4),
-            "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd_only,
+            "roofline": roof, "peaks": peaks, "cpu_baseline": cpu, "forward_only": fwd_only, "extra": extra,
         }
         print(json.dumps(out))
     if world > 1:

@@ -66,6 +66,9 @@ int sy11_get_option(const char* name, int32_t* value);
 int64_t sy11_tune_export(void* buf, int64_t capacity_bytes);
 int sy11_tune_import(const void* buf, int64_t bytes);
 int sy11_tune_clear(void);
+/* Measurement helper (bench.py `peaks`): a pure-MFMA loop, `iters` x 8 v_mfma_f32_32x32x16_f16 per wave, 4 waves per
+ * workgroup, no memory traffic.  FLOPs per launch = workgroups * 4 * iters * 8 * 32768; out: workgroups * 4 floats.     */
+int sy11_peak_mfma_f16(int32_t workgroups, int32_t iters, float* out, void* stream);
 
 /* ---- convolution (replaces nn.Conv2d inside Conv.forward / forward_fuse, nn/modules/conv.py:79-83,
  *      and the bare nn.Conv2d heads of Detect, nn/modules/head.py:44-55) -------------------------------- */

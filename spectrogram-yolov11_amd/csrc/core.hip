@@ -98,3 +98,35 @@ extern "C" int sy11_tune_clear(void) {
   }
   return SY11_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ measured peak (bench.py)
+// Pure-MFMA loop: every wave issues `iters` x 8 back-to-back v_mfma_f32_32x32x16_f16 on register operands (4 independent
+// accumulators, no memory traffic) — the matrix-core throughput the chip actually sustains at the clock it holds under this
+// load, to set beside the datasheet-class 2.5 PFLOP/s.  out[wave] receives a checksum so the loop cannot be optimised away.
+__global__ __launch_bounds__(256) void peak_mfma_f16_kernel(int iters, float* __restrict__ out) {
+  f16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (i + 1)); }
+  f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;
+}
+// FLOPs of one launch = workgroups * 4 waves * iters * 8 * (2 * 32 * 32 * 16); out: workgroups * 4 floats
+extern "C" int sy11_peak_mfma_f16(int32_t workgroups, int32_t iters, float* out, void* stream) {
+  SY11_REQUIRE(workgroups > 0 && iters > 0 && out, "peak_mfma_f16: bad argument");
+  hipLaunchKernelGGL(peak_mfma_f16_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, out);
+  SY11_LAUNCH_CHECK("peak_mfma_f16");
+  return SY11_OK;
+}

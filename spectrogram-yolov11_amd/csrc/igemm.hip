@@ -597,7 +597,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
   while (bn > 32 && (long)cdiv(a.M, 128) * cdiv(a.N, bn) < 512) bn >>= 1;
   int cfg = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
   if (forced >= 0 && cfg_legal<T>(a, forced)) return launch_cfg<T>(a, st, forced);
-  if (sy11tune::enabled() && dbg == 0) {
+  if (dbg == 0) {                    // a recorded / imported pick is honoured even with measuring off ("tune" 0 only stops NEW measurements)
     sy11tune::Cache& cache = sy11tune::cache(0);
     const int key[] = {(int)sizeof(T), a.M, a.N, a.K, a.C, a.T, a.sy, a.sx, a.IW, a.OW, a.x_ld, a.y_ld, a.dense_out,
                        (int)(a.flags & SY11_EPI_OUT_F32)};
@@ -605,7 +605,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
     int hit;
     if (cache.get(h, &hit)) {
       if (cfg_legal<T>(a, hit)) cfg = hit;
-    } else if (!sy11tune::capturing(st)) {
+    } else if (sy11tune::enabled() && !sy11tune::capturing(st)) {
       int cands[IGEMM_NCFG], nc = 0;
       for (int c = 0; c < IGEMM_NCFG; ++c) {
         const int ct = c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c)));

@@ -478,7 +478,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
   const int forced = sy11_opt(OPT_WGRAD_CFG);
   const int ncfg = d->dtype == SY11_F32 ? 8 : WGRAD_NCFG;
   if (forced >= 0 && forced < ncfg) return wgrad_launch_cfg(a, d->dtype, st, forced);
-  if (sy11tune::enabled()) {
+  {                                  // a recorded / imported pick is honoured even with measuring off
     sy11tune::Cache& cache = sy11tune::cache(1);
     static float* scratch = nullptr;
     static size_t scratch_elems = 0;
@@ -487,7 +487,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
     int hit;
     if (cache.get(h, &hit)) {
       cfg = hit;
-    } else if (!sy11tune::capturing(st)) {
+    } else if (sy11tune::enabled() && !sy11tune::capturing(st)) {
       const size_t need = (size_t)a.N * a.K;
       if (need > scratch_elems) {                       // candidates accumulate with atomics: measure into a scratch dW
         if (scratch) (void)hipFree(scratch);

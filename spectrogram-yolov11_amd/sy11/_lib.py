@@ -87,6 +87,7 @@ SIGNATURES.update({
     "sy11_get_option": [C.c_char_p, C.POINTER(C.c_int32)],
     "sy11_tune_import": [_vp, _i64],
     "sy11_tune_clear": [],
+    "sy11_peak_mfma_f16": [_i32, _i32, _vp, _vp],
 })
 OTHER = {"sy11_version": ([], C.c_int), "sy11_last_error": ([], C.c_char_p),
          "sy11_nms_workspace_bytes": ([_i32], C.c_size_t),
@@ -118,6 +119,14 @@ def load():
         fn.argtypes = args
         fn.restype = res
     _lib = lib
+    # tile-pick tables across processes (profiling passes that must run the kernels a normal run picked): SY11_TUNE_LOAD=<file>
+    # imports at load, SY11_TUNE_SAVE=<file> exports at interpreter exit
+    src, dst = os.environ.get("SY11_TUNE_LOAD"), os.environ.get("SY11_TUNE_SAVE")
+    if src and Path(src).exists():
+        tune_import(Path(src).read_bytes())
+    if dst:
+        import atexit
+        atexit.register(lambda: Path(dst).write_bytes(tune_export()))
     return lib
 
 
