@@ -1,0 +1,354 @@
+// conv3x3.hip — halo-tiled 3x3 convolution (stride 1 and 2, f16) on MFMA for gfx950: forward and stride-1 data gradient.
+//
+// Why a second conv kernel.  The generic implicit GEMM (igemm.hip) gathers the A operand tap by tap: a 128-pixel tile pulls
+// 9 x 128 pixel rows per channel slab through the CU's L1 although they are (TH+2) x (TW+2) distinct pixels.  r02 ablations
+// showed what bounds those kernels: not HBM, not the MFMA pipe, not DMA latency (deeper rings change nothing) but the bytes a CU
+// can take in from L2 into LDS per unit time (~50-70 GB/s per CU, MI355X_MICROARCH.md "gather into LDS").  So the lever is bytes
+// per FLOP.  Here a workgroup owns a 2-D tile of TH x TW output pixels (8x16, or whole rows of a 20- / 40-wide map) and loads,
+// per 32-channel slab, the input PATCH that tile needs — ((TH-1)S+3) x ((TW-1)S+3) pixels, zero-filled outside the image — ONCE;
+// the nine taps read it at nine row offsets.  A bytes per tile and slab: 180 rows instead of 1152 (stride 1), 561 instead of 1152
+// (stride 2).  The filter rows still stream per (slab, tap) through a 4-deep ring.
+//
+// LDS image of the patch: one 64-byte row per input pixel (32 channels), rows XOR-swizzled on the source side exactly as in
+// igemm.hip.  For stride 2 the columns of a patch row are stored de-interleaved (even x first, then odd x): a tap reads x = 2*tx + dx,
+// i.e. always one parity, so the 16 lanes of a fragment read hit 16 CONSECUTIVE rows again (conflict-free) instead of every other one.
+// Padding needs no masks in the MFMA loop: out-of-image patch pixels are fetched with an out-of-range buffer offset (hardware zeros).
+//
+// Waves are specialised for the copies only (every wave does MFMAs): waves 0-1 issue the filter stages, waves 2-3 the patch of the
+// NEXT slab in six slices during taps 0..5 — vmcnt counts per wave, so each role waits for its own copies with a trivial count and the
+// stage barrier publishes them.
+#include "igemm_args.h"
+#include <type_traits>
+
+typedef int h_rsrc_t __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void h_dma16(unsigned lds_addr, unsigned voff, h_rsrc_t rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+static __device__ __forceinline__ h_rsrc_t h_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  h_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32) & 0xffff);
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+static __device__ __forceinline__ void h_mma(const uint4& a, const uint4& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int N> static __device__ __forceinline__ void h_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// EPI bits as in igemm.hip: 1 BN statistics, 2 bias, 4 SiLU, 8 accumulate into y
+template <int S, int TH, int TW, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void halo3x3_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y) {
+  typedef _Float16 T;
+  constexpr int BM = 128, KB = 64, RPI = 16;
+  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
+  constexpr int PWh = S == 2 ? (PW + 1) / 2 : PW, PWp = S == 2 ? 2 * PWh : PW;    // row pitch of the patch image (pixels)
+  constexpr int PR = PH * PWp, NIA = (PR + RPI - 1) / RPI;
+  constexpr int NAW = (NIA + 1) / 2;              // patch copies (1 KiB each) per patch-loader wave and slab
+  constexpr int A_BYTES = 2 * NAW * RPI * KB;     // both loader waves issue NAW copies: with NIA odd the last one is a zero-filled pad row block
+  constexpr int CH = (NAW + 5) / 6;               // ... issued per tap, during taps 0..5
+  constexpr int NSTB = 4, B_BYTES = BN * KB;
+  constexpr int BPW = (BN / RPI + 1) / 2;          // filter copies per filter-loader wave and stage
+  constexpr int NVALID = TH * TW;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(WM * WN == 4 && MI >= 1 && NI >= 1 && NVALID <= BM, "tile layout");
+  static_assert(BM * BN * 2 <= 2 * A_BYTES + NSTB * B_BYTES, "epilogue staging must fit the dead operand buffers");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + NSTB * B_BYTES];
+  __shared__ float s_red[2 * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool is_b = wave_u < 2;                   // waves 0-1: filter stages; waves 2-3: patches
+  const int wr = wave_u & 1;
+  // XCD-aware order (workgroups b, b+8, ... share an XCD): a contiguous run of neighbouring tiles per XCD shares halo lines in its L2
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % a.tiles_n;
+  int tq = bid / a.tiles_n;
+  const int tile_x = tq % tiles_x;
+  tq /= tiles_x;
+  const int tile_y = tq % tiles_y;
+  const int img = tq / tiles_y;
+  const int oy0 = tile_y * TH, ox0 = tile_x * TW, bn0 = tile_n * BN;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+
+  for (int i = tid; i < 2 * BN; i += 256) s_red[i] = 0.f;
+
+  // per-tap constants (wave-uniform): row offset inside the patch image, byte offset of the tap's filter columns
+  int toff[9], wtap[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int dyp = a.tap_dy[t] + 1, dxp = a.tap_dx[t] + 1;
+    toff[t] = dyp * PWp + (S == 1 ? dxp : (dxp == 1 ? PWh : (dxp == 2 ? 1 : 0)));
+    wtap[t] = a.tap_w[t] * a.C * 2;
+  }
+  const h_rsrc_t xr = h_make_rsrc(a.x, a.x_bytes), wr_ = h_make_rsrc(a.w, a.w_bytes);
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned sB_base = smem_base + 2 * A_BYTES;
+  const int lrow = lane >> 2, lphys = lane & 3;
+
+  // ---- copy descriptors, hoisted.  Filter loader: BPW copies per stage; patch loader: NAW copies per slab.
+  int b_off[BPW];
+  int a_off[NAW];
+  if (is_b) {
+#pragma unroll
+    for (int k = 0; k < BPW; ++k) {
+      const int rl = (wr * BPW + k) * RPI + lrow, n = bn0 + rl;
+      const int logical = lphys ^ ((rl >> 2) & 3);
+      b_off[k] = (rl < BN && n < a.N) ? n * a.wK * 2 + logical * 16 : (int)OOB;
+    }
+#pragma unroll
+    for (int k = 0; k < NAW; ++k) a_off[k] = (int)OOB;
+  } else {
+#pragma unroll
+    for (int k = 0; k < BPW; ++k) b_off[k] = (int)OOB;
+#pragma unroll
+    for (int k = 0; k < NAW; ++k) {
+      const int j = wr + 2 * k, p = j * RPI + lrow;
+      const int logical = lphys ^ ((p >> 2) & 3);
+      const int py = p / PWp, rem = p - py * PWp;
+      int px;
+      if (S == 1) {
+        px = rem;
+      } else {
+        const int par = rem >= PWh ? 1 : 0;
+        px = 2 * (rem - par * PWh) + par;
+      }
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = j < NIA && p < PR && px < PW && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      a_off[k] = ok ? ((img * a.IH + iy) * a.IW + ix) * a.x_ld * 2 + logical * 16 : (int)OOB;
+    }
+  }
+
+  // ---- fragment addressing
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 31, fh = lane >> 5;
+  int arow0[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * (BM / WM) + i * 32 + frow;
+    const int ty = r / TW, tx = r - ty * TW;
+    arow0[i] = r < NVALID ? ty * S * PWp + tx : 0;      // rows past the tile compute on pixel 0 and are never stored
+  }
+  int fb_off[NI][2];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int r = wn * (BN / WN) + j * 32 + frow;
+      fb_off[j][g] = r * KB + (((2 * g + fh) ^ ((r >> 2) & 3)) << 4);
+    }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nslab = a.C >> 5, nstage = nslab * 9;
+
+  auto issue_b = [&](int bufq, int tapbytes, int slab) {      // one filter stage: BN rows x 64 bytes
+    const unsigned dst = sB_base + bufq * B_BYTES + (wr * BPW) * (RPI * KB);
+    const int ko = tapbytes + slab * KB;
+#pragma unroll
+    for (int k = 0; k < BPW; ++k) h_dma16(dst + k * (RPI * KB), b_off[k] >= 0 ? (unsigned)(b_off[k] + ko) : OOB, wr_);
+  };
+  auto issue_a = [&](int k0, int k1, int slab) {               // copies k0..k1-1 of this wave's share of patch(slab)
+    const unsigned dst = smem_base + (slab & 1) * A_BYTES;
+#pragma unroll
+    for (int k = 0; k < NAW; ++k)
+      if (k >= k0 && k < k1) h_dma16(dst + (wr + 2 * k) * (RPI * KB), a_off[k] >= 0 ? (unsigned)(a_off[k] + slab * KB) : OOB, xr);
+  };
+
+  __syncthreads();                                   // s_red zeroed before anybody can reach the epilogue
+  if (is_b) {
+#pragma unroll
+    for (int q = 0; q < NSTB - 1; ++q)
+      if (q < nstage) issue_b(q & 3, wtap[q], 0);    // stages 0..2 are taps 0..2 of slab 0
+  } else {
+    issue_a(0, NAW, 0);
+  }
+
+  for (int slab = 0; slab < nslab; ++slab) {
+    const unsigned char* sAc = smem + (slab & 1) * A_BYTES;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int q = slab * 9 + t;
+      if (is_b) {                                    // stage q landed; the (up to two) younger stages may stay in flight
+        const int later = nstage - 1 - q;
+        if (later >= 2) h_wait_vm<2 * BPW>();
+        else if (later == 1) h_wait_vm<BPW>();
+        else h_wait_vm<0>();
+      } else if (t == 0) {
+        h_wait_vm<0>();                              // the whole patch of this slab (issued during the previous slab)
+      }
+      __builtin_amdgcn_s_barrier();
+      if (is_b) {
+        const int t3 = (t + 3) % 9, s3 = slab + (t + 3) / 9;
+        if (q + 3 < nstage) issue_b((s3 + t3) & 3, wtap[t3], s3);
+      } else if (t < 6 && slab + 1 < nslab) {
+        issue_a(t * CH, (t + 1) * CH < NAW ? (t + 1) * CH : NAW, slab + 1);
+      }
+      const unsigned char* sBc = smem + 2 * A_BYTES + ((slab + t) & 3) * B_BYTES;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        uint4 fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = arow0[i] + toff[t];
+          fa[i] = *(const uint4*)(sAc + row * KB + (((2 * g + fh) ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[j] = *(const uint4*)(sBc + fb_off[j][g]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) h_mma(fa[i], fb[j], acc[i][j]);
+      }
+    }
+  }
+  __syncthreads();                                   // all fragment reads done before the epilogue reuses the operand buffers
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  constexpr bool do_stats = EPI & 1, has_bias = EPI & 2, silu = EPI & 4, accum = EPI & 8;
+  constexpr int ROWB = BN * 2, CPR = ROWB / 16;
+  float ssum[NI], ssq[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) ssum[j] = ssq[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+      const int ty = rl / TW, tx = rl - ty * TW;
+      const bool rok = rl < NVALID && oy0 + ty < a.OH && ox0 + tx < a.OW;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int cl = wn * (BN / WN) + j * 32 + frow;
+        const int n = bn0 + cl;
+        float v = acc[i][j][e];
+        if (do_stats && rok && n < a.N) { ssum[j] += v; ssq[j] += v * v; }
+        if (has_bias && n < a.N) v += a.bias[n];
+        if (silu) v = silu_f(v);
+        *(T*)(smem + rl * ROWB + cl * 2) = (T)v;
+      }
+    }
+  __syncthreads();
+  for (int idx = tid; idx < NVALID * CPR; idx += 256) {
+    const int rl = idx / CPR, ch = idx - rl * CPR;
+    const int ty = rl / TW, tx = rl - ty * TW;
+    const int oy = oy0 + ty, ox = ox0 + tx, n = bn0 + ch * 8;
+    if (oy >= a.OH || ox >= a.OW || n >= a.N || a.debug == 5) continue;      // debug 5 = tuner dry run of an accumulating epilogue
+    uint4 v = *(const uint4*)(smem + rl * ROWB + ch * 16);
+    unsigned char* gp = (unsigned char*)a.y + (((long)(img * a.OH + oy) * a.OW + ox) * a.y_ld + n) * 2;
+    if (accum) {
+      const uint4 o = *(const uint4*)gp;
+      f16x8 x = __builtin_bit_cast(f16x8, v), y = __builtin_bit_cast(f16x8, o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = (_Float16)((float)x[k] + (float)y[k]);
+      v = __builtin_bit_cast(uint4, x);
+    }
+    *(uint4*)gp = v;
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float s1 = ssum[j] + __shfl_xor(ssum[j], 32);
+      const float s2 = ssq[j] + __shfl_xor(ssq[j], 32);
+      if (fh == 0) {
+        const int col = wn * (BN / WN) + j * 32 + frow;
+        atomicAdd(&s_red[col], s1);
+        atomicAdd(&s_red[BN + col], s2);
+      }
+    }
+    __syncthreads();
+    if (tid < BN && bn0 + tid < a.N) {
+      const long so = (long)(blockIdx.x % a.stat_slots) * a.stat_stride;
+      atomicAdd(a.stat_sum + so + bn0 + tid, s_red[tid]);
+      atomicAdd(a.stat_sq + so + bn0 + tid, s_red[BN + tid]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int halo_epi(const IgemmArgs& a) {
+  return (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
+         ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
+}
+static bool halo_tile(int OW, int* th, int* tw) {
+  if (OW % 16 == 0) { *th = 8; *tw = 16; return true; }
+  if (OW == 20) { *th = 6; *tw = 20; return true; }
+  if (OW == 40) { *th = 3; *tw = 40; return true; }
+  return false;
+}
+
+bool sy11_halo3x3_legal(const IgemmArgs& a, int bn) {
+  if (a.T != 9 || a.K != 9 * a.C || a.C % 32 || a.N % 8 || !a.dense_out || !a.vec_out || a.tail.ticket || (a.debug != 0 && a.debug != 5)) return false;
+  if (!((a.sy == 1 && a.sx == 1) || (a.sy == 2 && a.sx == 2))) return false;
+  const int epi = halo_epi(a);
+  if (a.sy == 1 ? !(epi == 0 || epi == 1 || epi == 8 || epi == 6) : !(epi == 0 || epi == 1 || epi == 6)) return false;
+  unsigned seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    const int dy = a.tap_dy[t] + 1, dx = a.tap_dx[t] + 1;
+    if (dy < 0 || dy > 2 || dx < 0 || dx > 2) return false;
+    seen |= 1u << (dy * 3 + dx);
+  }
+  if (seen != 0x1ff) return false;
+  int th, tw;
+  if (!halo_tile(a.OW, &th, &tw)) return false;
+  if (bn != 128 && bn != 64 && bn != 32) return false;
+  if (bn > 32 && bn >= 2 * a.N) return false;          // a tile more than twice the channel count is pure waste
+  return true;
+}
+
+template <int S, int TH, int TW, int BN, int WM, int WN>
+static void halo_launch_epi(const IgemmArgs& a, int epi, dim3 grid, hipStream_t st, int tx, int ty) {
+  dim3 block(256);
+  switch (epi) {
+    case 0: hipLaunchKernelGGL((halo3x3_kernel<S, TH, TW, BN, WM, WN, 0>), grid, block, 0, st, a, tx, ty); break;
+    case 1: hipLaunchKernelGGL((halo3x3_kernel<S, TH, TW, BN, WM, WN, 1>), grid, block, 0, st, a, tx, ty); break;
+    case 6: hipLaunchKernelGGL((halo3x3_kernel<S, TH, TW, BN, WM, WN, 6>), grid, block, 0, st, a, tx, ty); break;
+    case 8:
+      if constexpr (S == 1) hipLaunchKernelGGL((halo3x3_kernel<S, TH, TW, BN, WM, WN, 8>), grid, block, 0, st, a, tx, ty);
+      break;
+    default: break;
+  }
+}
+template <int S, int TH, int TW>
+static void halo_launch_bn(const IgemmArgs& a, int bn, int epi, dim3 grid, hipStream_t st, int tx, int ty) {
+  if (bn == 128) halo_launch_epi<S, TH, TW, 128, 2, 2>(a, epi, grid, st, tx, ty);
+  else if (bn == 64) halo_launch_epi<S, TH, TW, 64, 4, 1>(a, epi, grid, st, tx, ty);
+  else halo_launch_epi<S, TH, TW, 32, 4, 1>(a, epi, grid, st, tx, ty);
+}
+template <int S>
+static void halo_launch_tile(const IgemmArgs& a, int bn, int epi, int tw, dim3 grid, hipStream_t st, int tx, int ty) {
+  if (tw == 16) halo_launch_bn<S, 8, 16>(a, bn, epi, grid, st, tx, ty);
+  else if (tw == 20) halo_launch_bn<S, 6, 20>(a, bn, epi, grid, st, tx, ty);
+  else halo_launch_bn<S, 3, 40>(a, bn, epi, grid, st, tx, ty);
+}
+
+int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn, hipStream_t st) {
+  if (!sy11_halo3x3_legal(a_in, bn)) SY11_FAIL(SY11_EUNSUPPORTED, "halo3x3: problem not covered by the halo-tiled kernel");
+  IgemmArgs a = a_in;
+  int th, tw;
+  halo_tile(a.OW, &th, &tw);
+  const int B = a.M / (a.OH * a.OW);
+  const int tx = cdiv(a.OW, tw), ty = cdiv(a.OH, th);
+  a.tiles_n = cdiv(a.N, bn);
+  const long nwg = (long)B * tx * ty * a.tiles_n;
+  if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "halo3x3: bad grid %ld", nwg);
+  dim3 grid((unsigned)nwg);
+  const int epi = halo_epi(a);
+  if (a.sy == 1) halo_launch_tile<1>(a, bn, epi, tw, grid, st, tx, ty);
+  else halo_launch_tile<2>(a, bn, epi, tw, grid, st, tx, ty);
+  SY11_LAUNCH_CHECK("halo3x3");
+  return SY11_OK;
+}

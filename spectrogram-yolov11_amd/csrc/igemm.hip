@@ -19,38 +19,11 @@
 #include "common.h"
 #include "tune.h"
 #include "bn_tail.h"
+#include "igemm_args.h"
 #include <stdlib.h>
 #include <type_traits>
 
 __device__ uint4 g_zero16;   // zero page: source of padded / out-of-range 16-byte chunks (zero-initialised)
-
-struct IgemmArgs {
-  const void* x;
-  const void* w;
-  void* y;
-  const float* bias;
-  float* stat_sum;
-  float* stat_sq;
-  int M, N, K, C, T;
-  int wK;                 // elements between consecutive filter rows (full T*C of the stored filter)
-  int x_ld, y_ld;
-  int IH, IW, OH, OW;
-  int sy, sx;
-  int OHF, OWF, oy_mul, oy_add, ox_mul, ox_add;
-  int dense_out;          // 1: output offset is m*y_ld (no decode)
-  int tiles_n;
-  int chan_major;     // K loop order: 1 = taps innermost (needs C % stage == 0), 0 = channels innermost
-  int stat_slots;
-  int stat_stride;        // floats between consecutive stat slots (= channel count of the WHOLE stat row)
-  unsigned x_bytes, w_bytes;   // extents of the x / w views in bytes (buffer descriptors range-check against them)
-  int debug;              // diagnostic builds only: 1 = skip the LDS-DMA issue after the prologue, 2 = skip the MFMAs
-  int vec_out;            // 1: output rows are 16-byte addressable -> LDS-transposed wide stores
-  unsigned flags;
-  BnTailDev tail;         // BN statistics finalised by the last workgroup (ticket == nullptr: off)
-  signed char tap_dy[64];
-  signed char tap_dx[64];
-  signed char tap_w[64];
-};
 
 template <typename T> struct Mma;
 template <> struct Mma<float> {
@@ -81,6 +54,13 @@ template <> struct Mma<__bf16> {
 typedef int dma_rsrc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, dma_rsrc_t rsrc) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+// cache-policy variants of the same copy: sc1 = served from L2 without allocating in this CU's L1; nt = non-temporal
+__device__ __forceinline__ void lds_dma16_sc1(unsigned lds_addr, unsigned voff, dma_rsrc_t rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_nt(unsigned lds_addr, unsigned voff, dma_rsrc_t rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ dma_rsrc_t make_dma_rsrc(const void* base, unsigned bytes) {
   const unsigned long long p = (unsigned long long)base;
@@ -183,6 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   // what the 32 KB L1 keeps — so every tap goes to L2 again.  Channel-major (the T taps of one slab back to back) makes the
   // next stage read the rows the previous one just fetched, shifted by one pixel: most of them are still in L1.
   const bool chan_major = a.chan_major && a.T > 1 && a.C % BK == 0;
+  const int bpol = __builtin_amdgcn_readfirstlane(a.bpol);
   const bool b_issue = (BN >= RPP) || (wave_u * RPI < BN);         // BN < rows-per-pass: only waves covering real rows issue
   __syncthreads();  // tap tables visible
 
@@ -199,8 +180,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
       lds_dma16(sa + i * (RPP * KB), ok ? (unsigned)(a_off[i] + xo) : OOB, xr);
     }
     if (b_issue) {
+      // filter rows: every workgroup of the launch streams the same rows once per tile — with the default policy they also
+      // pass through (and evict from) the 32 KB L1 that could otherwise keep the tile's input rows across the taps of a slab
 #pragma unroll
-      for (int i = 0; i < BPASS; ++i) lds_dma16(sb + i * (RPP * KB), (kvalid && b_off[i] >= 0) ? (unsigned)(b_off[i] + wo) : OOB, wr_);
+      for (int i = 0; i < BPASS; ++i) {
+        const unsigned off = (kvalid && b_off[i] >= 0) ? (unsigned)(b_off[i] + wo) : OOB;
+        if (bpol == 1) lds_dma16_sc1(sb + i * (RPP * KB), off, wr_);
+        else if (bpol == 2) lds_dma16_nt(sb + i * (RPP * KB), off, wr_);
+        else lds_dma16(sb + i * (RPP * KB), off, wr_);
+      }
     }
     if (chan_major) {                             // all taps of one channel slab back to back (see chan_major above)
       const bool wrap = kt + 1 >= a.T;
@@ -498,7 +486,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // 4..6 = the first three with 128-byte K stages (half the barriers per K, 2 workgroups per CU instead of 4)
 // 7, 8 = persistent 1x1 kernel (igemm1x1.hip) with 128 / 64 channels per workgroup
 // 9..11 = the first three with a 4-deep ring of 64-byte stages (3 stages in flight); 12..14 = 128-byte stages, 3-deep ring
-constexpr int IGEMM_NCFG = 15;
+// 15, 16 = halo-tiled 3x3 kernel (conv3x3.hip) with the widest / the next narrower channel tile
+constexpr int IGEMM_NCFG = 17;
+static int halo_bn(const IgemmArgs& a, int cfg) {
+  const int wide = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  return cfg == 15 ? wide : (wide > 32 ? wide / 2 : 0);
+}
 int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq, int M, int N, int K, int x_ld,
                           int y_ld, int stat_slots, int stat_stride, unsigned x_bytes, unsigned w_bytes, int epi, int nostore, int bn,
                           hipStream_t st, const float* bias);
@@ -509,6 +502,10 @@ static int epi_code(const IgemmArgs& a) {
 template <typename T>
 static bool cfg_legal(const IgemmArgs& a, int cfg) {
   if (cfg < 0 || cfg >= IGEMM_NCFG) return false;
+  if (cfg == 15 || cfg == 16) {
+    const int bn = halo_bn(a, cfg);
+    return std::is_same<T, _Float16>::value && bn > 0 && sy11_halo3x3_legal(a, bn);
+  }
   if (cfg == 7 || cfg == 8) {
     const int epi = epi_code(a), bn = cfg == 7 ? 128 : 64;
     if (std::is_same<T, float>::value || a.T != 1 || a.tap_dy[0] || a.tap_dx[0] || a.sy != 1 || a.sx != 1 || !a.dense_out || !a.vec_out) return false;
@@ -531,6 +528,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
 
 template <typename T>
 static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
+  if (cfg == 15 || cfg == 16) return sy11_halo3x3_launch(a, halo_bn(a, cfg), st);
   if (cfg == 7 || cfg == 8)
     return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
                                  a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st, a.bias);
@@ -592,10 +590,19 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
   const int forced = sy11_opt(OPT_IGEMM_CFG);
   a.debug = dbg;
   a.chan_major = sy11_opt(OPT_IGEMM_KORDER);
+  a.bpol = sy11_opt(OPT_IGEMM_BPOL);
   // static heuristic: widest channel tile the layer fills; small maps (20x20 / 40x40) narrow it until the grid covers the chip
   int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   while (bn > 32 && (long)cdiv(a.M, 128) * cdiv(a.N, bn) < 512) bn >>= 1;
   int cfg = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
+  // 3x3 stride 1: the halo-tiled kernel moves 1.7-2.3x fewer bytes into LDS and won every such layer of yolo11s in the r02 sweeps
+  // (-20..45 %); stride 2 is a wash (the tuner decides).  Narrower channel tile when the wide one leaves CUs without a workgroup.
+  if (a.sy == 1 && a.T == 9 && cfg_legal<T>(a, 15)) {
+    int th = 8, tw = 16;
+    if (a.OW == 20) { th = 6; tw = 20; } else if (a.OW == 40) { th = 3; tw = 40; }
+    const long wgs = (long)(a.M / (a.OH * a.OW)) * cdiv(a.OH, th) * cdiv(a.OW, tw) * cdiv(a.N, halo_bn(a, 15));
+    cfg = (wgs < 400 && cfg_legal<T>(a, 16)) ? 16 : 15;
+  }
   if (forced >= 0 && cfg_legal<T>(a, forced)) return launch_cfg<T>(a, st, forced);
   if (dbg == 0) {                    // a recorded / imported pick is honoured even with measuring off ("tune" 0 only stops NEW measurements)
     sy11tune::Cache& cache = sy11tune::cache(0);
@@ -610,7 +617,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
       for (int c = 0; c < IGEMM_NCFG; ++c) {
         const int ct = c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c)));
         const int cbn = ct == 1 ? 64 : (ct == 2 ? 32 : 128);
-        if (cbn > 32 && cbn >= 2 * a.N) continue;                        // tile more than twice the channel count: pure waste
+        if (c < 15 && cbn > 32 && cbn >= 2 * a.N) continue;              // tile more than twice the channel count: pure waste
         if (cfg_legal<T>(a, c)) cands[nc++] = c;
       }
       // measuring must leave no trace: no BN statistics; an accumulating epilogue runs with its global stores disabled

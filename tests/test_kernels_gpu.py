@@ -120,6 +120,13 @@ CFG_CASES = [
     (3, 256, 12, 12, 96, 1, 1),      # 1x1, K = 256
     (2, 128, 18, 18, 64, 3, 2),      # stride 2: dgrad = 4 parity launches with 1 / 2 / 2 / 4 taps
     (4, 32, 40, 40, 32, 1, 1),       # K = 32: shorter than every deep ring (those configurations must refuse, not misbehave)
+    # shapes the halo-tiled 3x3 kernel (cfg 15 / 16) takes: output width a multiple of 16, or exactly 20 / 40
+    (2, 64, 32, 32, 96, 3, 2),       # stride 2 -> 16x16, N = 96 (partial channel tile), de-interleaved patch columns
+    (1, 32, 40, 40, 32, 3, 1),       # whole-row tiles of a 40-wide map (3 x 40), one channel slab, N = 32
+    (2, 96, 16, 48, 64, 3, 1),       # 8 x 16 tiles, three slabs, non-square map
+    (1, 64, 80, 80, 40, 3, 2),       # stride 2 -> 40x40 (3 x 40 tiles over an 81-column patch)
+    (1, 32, 31, 39, 64, 3, 2),       # stride 2 from odd input sizes -> 16 x 20: the patch runs past the right / bottom border
+    (3, 128, 20, 20, 128, 3, 1),     # 6 x 20 tiles on the 20x20 maps of the model (partial last tile row)
 ]
 
 
@@ -146,7 +153,7 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
     tune0 = _lib.get_option("tune")
     try:
         _lib.set_option("tune", 0)
-        for cfg in range(15):
+        for cfg in range(17):
             _lib.set_option("igemm_cfg", cfg)
             y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
             ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
