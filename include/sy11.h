@@ -51,13 +51,15 @@ typedef struct sy11_conv_desc {
 int sy11_version(void);
 const char* sy11_last_error(void);
 
-/* ---- run-time options (no reference counterpart; they stand where the reference has cfg keys / torch switches):
- *   "deterministic" 0|1   cfg/default.yaml:29 `deterministic`, utils/torch_utils.py:474-492 (ordered reductions instead of
- *                         floating-point atomics: bit-identical reruns)
- *   "tune" 0|1            first-call tile autotuner (cf. torch.backends.cudnn.benchmark, utils/torch_utils.py:488)
- *   "tune_log" 0|1, "igemm_cfg" / "wgrad_cfg" (-1 = automatic, else force one tile configuration), "igemm_korder" 0|1.
+/* ---- run-time options (no reference counterpart; "tune" stands where the reference has torch.backends.cudnn.benchmark,
+ *      utils/torch_utils.py:488):
+ *   "tune" 0|1            first-call tile autotuner (0: no NEW measurements; recorded / imported picks are still honoured)
+ *   "tune_log" 0|1, "igemm_cfg" / "wgrad_cfg" (-1 = automatic, else force one tile configuration), "igemm_korder" 0|1,
+ *   "igemm_deep" 0|1|2 (deeper LDS rings), "igemm_bpol" 0|1|2 (cache policy of the filter-row copies).
  * Defaults come from the environment (SY11_TUNE, SY11_TUNE_LOG, SY11_IGEMM_CFG, SY11_WGRAD_CFG, SY11_IGEMM_KORDER,
- * SY11_DETERMINISTIC).  Process-wide; set them between launches, not concurrently with them.                         */
+ * SY11_IGEMM_DEEP, SY11_IGEMM_BPOL).  Process-wide; set them between launches, not concurrently with them.
+ * (There is no "deterministic" switch: sums over pixels use f32 atomics in LDS and in HBM — see DESIGN.md §5 for what an
+ * ordered mode would take; cfg/default.yaml:29 `deterministic` is therefore NOT honoured.)                              */
 int sy11_set_option(const char* name, int32_t value);
 int sy11_get_option(const char* name, int32_t* value);
 /* The autotuner's pick tables as a flat array of 16-byte records {u64 problem hash, i32 kind, i32 pick}: export on one

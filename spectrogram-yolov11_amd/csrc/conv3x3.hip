@@ -40,9 +40,10 @@ template <int N> static __device__ __forceinline__ void h_wait_vm() { asm volati
 
 // EPI bits as in igemm.hip: 1 BN statistics, 2 bias, 4 SiLU, 8 accumulate into y
 template <int S, int TH, int TW, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256) void halo3x3_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void halo3x3_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y) {
   typedef _Float16 T;
-  constexpr int BM = 128, KB = 64, RPI = 16;
+  constexpr int BM = TH * TW > 128 ? 256 : 128;    // MFMA rows per workgroup; tiles of up to 256 pixels halve the filter bytes per FLOP
+  constexpr int KB = 64, RPI = 16;
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
   constexpr int PWh = S == 2 ? (PW + 1) / 2 : PW, PWp = S == 2 ? 2 * PWh : PW;    // row pitch of the patch image (pixels)
@@ -283,14 +284,17 @@ static int halo_epi(const IgemmArgs& a) {
   return (a.stat_sum ? 1 : 0) | (a.bias ? 2 : 0) | ((a.flags & SY11_EPI_SILU) ? 4 : 0) | ((a.flags & SY11_EPI_ACCUM) ? 8 : 0) |
          ((a.flags & SY11_EPI_OUT_F32) ? 16 : 0);
 }
-static bool halo_tile(int OW, int* th, int* tw) {
-  if (OW % 16 == 0) { *th = 8; *tw = 16; return true; }
-  if (OW == 20) { *th = 6; *tw = 20; return true; }
-  if (OW == 40) { *th = 3; *tw = 40; return true; }
+static bool halo_tile(int OW, int OH, int big, int* th, int* tw) {
+  if (OW % 16 == 0) { *tw = 16; *th = (big && OH % 16 == 0) ? 16 : 8; return !big || *th == 16; }
+  if (OW == 20) { *tw = 20; *th = big ? 12 : 6; return true; }
+  if (OW == 40) { *tw = 40; *th = big ? 6 : 3; return true; }
   return false;
 }
 
-bool sy11_halo3x3_legal(const IgemmArgs& a, int bn) {
+// bn = channels per workgroup (128 / 64 / 32); +1000 = the 256-pixel tiles (stride 1 only)
+bool sy11_halo3x3_legal(const IgemmArgs& a, int bn_code) {
+  const int big = bn_code >= 1000, bn = bn_code % 1000;
+  if (big && (a.sy != 1 || bn < 64)) return false;
   if (a.T != 9 || a.K != 9 * a.C || a.C % 32 || a.N % 8 || !a.dense_out || !a.vec_out || a.tail.ticket || (a.debug != 0 && a.debug != 5)) return false;
   if (!((a.sy == 1 && a.sx == 1) || (a.sy == 2 && a.sx == 2))) return false;
   const int epi = halo_epi(a);
@@ -303,7 +307,7 @@ bool sy11_halo3x3_legal(const IgemmArgs& a, int bn) {
   }
   if (seen != 0x1ff) return false;
   int th, tw;
-  if (!halo_tile(a.OW, &th, &tw)) return false;
+  if (!halo_tile(a.OW, a.OH, big, &th, &tw)) return false;
   if (bn != 128 && bn != 64 && bn != 32) return false;
   if (bn > 32 && bn >= 2 * a.N) return false;          // a tile more than twice the channel count is pure waste
   return true;
@@ -326,20 +330,26 @@ template <int S, int TH, int TW>
 static void halo_launch_bn(const IgemmArgs& a, int bn, int epi, dim3 grid, hipStream_t st, int tx, int ty) {
   if (bn == 128) halo_launch_epi<S, TH, TW, 128, 2, 2>(a, epi, grid, st, tx, ty);
   else if (bn == 64) halo_launch_epi<S, TH, TW, 64, 4, 1>(a, epi, grid, st, tx, ty);
-  else halo_launch_epi<S, TH, TW, 32, 4, 1>(a, epi, grid, st, tx, ty);
+  else if constexpr (TH * TW <= 128) halo_launch_epi<S, TH, TW, 32, 4, 1>(a, epi, grid, st, tx, ty);
 }
 template <int S>
-static void halo_launch_tile(const IgemmArgs& a, int bn, int epi, int tw, dim3 grid, hipStream_t st, int tx, int ty) {
-  if (tw == 16) halo_launch_bn<S, 8, 16>(a, bn, epi, grid, st, tx, ty);
-  else if (tw == 20) halo_launch_bn<S, 6, 20>(a, bn, epi, grid, st, tx, ty);
-  else halo_launch_bn<S, 3, 40>(a, bn, epi, grid, st, tx, ty);
+static void halo_launch_tile(const IgemmArgs& a, int bn, int epi, int th, int tw, dim3 grid, hipStream_t st, int tx, int ty) {
+  if (tw == 16 && th == 8) halo_launch_bn<S, 8, 16>(a, bn, epi, grid, st, tx, ty);
+  else if (tw == 20 && th == 6) halo_launch_bn<S, 6, 20>(a, bn, epi, grid, st, tx, ty);
+  else if (tw == 40 && th == 3) halo_launch_bn<S, 3, 40>(a, bn, epi, grid, st, tx, ty);
+  else if constexpr (S == 1) {
+    if (tw == 16) halo_launch_bn<1, 16, 16>(a, bn, epi, grid, st, tx, ty);
+    else if (tw == 20) halo_launch_bn<1, 12, 20>(a, bn, epi, grid, st, tx, ty);
+    else halo_launch_bn<1, 6, 40>(a, bn, epi, grid, st, tx, ty);
+  }
 }
 
-int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn, hipStream_t st) {
-  if (!sy11_halo3x3_legal(a_in, bn)) SY11_FAIL(SY11_EUNSUPPORTED, "halo3x3: problem not covered by the halo-tiled kernel");
+int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn_code, hipStream_t st) {
+  if (!sy11_halo3x3_legal(a_in, bn_code)) SY11_FAIL(SY11_EUNSUPPORTED, "halo3x3: problem not covered by the halo-tiled kernel");
+  const int big = bn_code >= 1000, bn = bn_code % 1000;
   IgemmArgs a = a_in;
   int th, tw;
-  halo_tile(a.OW, &th, &tw);
+  halo_tile(a.OW, a.OH, big, &th, &tw);
   const int B = a.M / (a.OH * a.OW);
   const int tx = cdiv(a.OW, tw), ty = cdiv(a.OH, th);
   a.tiles_n = cdiv(a.N, bn);
@@ -347,8 +357,8 @@ int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn, hipStream_t st) {
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "halo3x3: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg);
   const int epi = halo_epi(a);
-  if (a.sy == 1) halo_launch_tile<1>(a, bn, epi, tw, grid, st, tx, ty);
-  else halo_launch_tile<2>(a, bn, epi, tw, grid, st, tx, ty);
+  if (a.sy == 1) halo_launch_tile<1>(a, bn, epi, th, tw, grid, st, tx, ty);
+  else halo_launch_tile<2>(a, bn, epi, th, tw, grid, st, tx, ty);
   SY11_LAUNCH_CHECK("halo3x3");
   return SY11_OK;
 }

@@ -487,10 +487,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // 7, 8 = persistent 1x1 kernel (igemm1x1.hip) with 128 / 64 channels per workgroup
 // 9..11 = the first three with a 4-deep ring of 64-byte stages (3 stages in flight); 12..14 = 128-byte stages, 3-deep ring
 // 15, 16 = halo-tiled 3x3 kernel (conv3x3.hip) with the widest / the next narrower channel tile
-constexpr int IGEMM_NCFG = 17;
+// 17, 18 = the same with 256-pixel tiles (stride 1): half the filter bytes per FLOP
+constexpr int IGEMM_NCFG = 19;
 static int halo_bn(const IgemmArgs& a, int cfg) {
   const int wide = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
-  return cfg == 15 ? wide : (wide > 32 ? wide / 2 : 0);
+  const int bn = (cfg == 15 || cfg == 17) ? wide : (wide > 32 ? wide / 2 : 0);
+  return bn == 0 ? 0 : (cfg >= 17 ? 1000 + bn : bn);
 }
 int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq, int M, int N, int K, int x_ld,
                           int y_ld, int stat_slots, int stat_stride, unsigned x_bytes, unsigned w_bytes, int epi, int nostore, int bn,
@@ -502,7 +504,7 @@ static int epi_code(const IgemmArgs& a) {
 template <typename T>
 static bool cfg_legal(const IgemmArgs& a, int cfg) {
   if (cfg < 0 || cfg >= IGEMM_NCFG) return false;
-  if (cfg == 15 || cfg == 16) {
+  if (cfg >= 15 && cfg <= 18) {
     const int bn = halo_bn(a, cfg);
     return std::is_same<T, _Float16>::value && bn > 0 && sy11_halo3x3_legal(a, bn);
   }
@@ -528,7 +530,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
 
 template <typename T>
 static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
-  if (cfg == 15 || cfg == 16) return sy11_halo3x3_launch(a, halo_bn(a, cfg), st);
+  if (cfg >= 15 && cfg <= 18) return sy11_halo3x3_launch(a, halo_bn(a, cfg), st);
   if (cfg == 7 || cfg == 8)
     return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
                                  a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st, a.bias);
@@ -600,7 +602,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
   if (a.sy == 1 && a.T == 9 && cfg_legal<T>(a, 15)) {
     int th = 8, tw = 16;
     if (a.OW == 20) { th = 6; tw = 20; } else if (a.OW == 40) { th = 3; tw = 40; }
-    const long wgs = (long)(a.M / (a.OH * a.OW)) * cdiv(a.OH, th) * cdiv(a.OW, tw) * cdiv(a.N, halo_bn(a, 15));
+    const long wgs = (long)(a.M / (a.OH * a.OW)) * cdiv(a.OH, th) * cdiv(a.OW, tw) * cdiv(a.N, halo_bn(a, 15) % 1000);
     cfg = (wgs < 400 && cfg_legal<T>(a, 16)) ? 16 : 15;
   }
   if (forced >= 0 && cfg_legal<T>(a, forced)) return launch_cfg<T>(a, st, forced);

@@ -33,6 +33,6 @@ struct IgemmArgs {
 };
 
 
-// halo-tiled 3x3 kernel (conv3x3.hip): bn = channels per workgroup (128 / 64 / 32); returns SY11_OK or a negative status
+// halo-tiled 3x3 kernel (conv3x3.hip): bn = channels per workgroup (128 / 64 / 32), + 1000 for the 256-pixel tiles; returns SY11_OK or a negative status
 bool sy11_halo3x3_legal(const IgemmArgs& a, int bn);
 int sy11_halo3x3_launch(const IgemmArgs& a, int bn, hipStream_t st);

@@ -156,7 +156,7 @@ def call(name: str, *args):
 
 
 def set_option(name: str, value: int):
-    """sy11_set_option: "deterministic", "tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder"."""
+    """sy11_set_option: "tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder", "igemm_deep", "igemm_bpol"."""
     check(load().sy11_set_option(name.encode(), int(value)), "sy11_set_option")
 
 

@@ -153,7 +153,7 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
     tune0 = _lib.get_option("tune")
     try:
         _lib.set_option("tune", 0)
-        for cfg in range(17):
+        for cfg in range(19):
             _lib.set_option("igemm_cfg", cfg)
             y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
             ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)

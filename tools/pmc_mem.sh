@@ -19,7 +19,7 @@ import csv, glob, collections
 acc = collections.defaultdict(float); n = collections.Counter()
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "igemm" not in r["Kernel_Name"] and "wgrad" not in r["Kernel_Name"]: continue
+        if not any(s in r["Kernel_Name"] for s in ("igemm", "wgrad", "halo3x3")): continue
         acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 for c in sorted(acc):
     print(f"   {c:36s} {acc[c] / n[c]:18.0f}  per launch")
