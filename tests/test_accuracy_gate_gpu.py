@@ -16,7 +16,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
 
 def test_hip_trainer_and_oracle_trainer_reach_the_same_map_on_held_out_iq_scenes():
     import accuracy_gate as A
-    r = A.run("tiny", steps=160, batch=8, n_train=48, n_val=24, curve_steps=10)
+    # 320 steps: near the plateau (at 160 steps mAP still rises ~0.1 per 40 steps); 64 held-out scenes and the mean of two HIP
+    # runs: HIP training is not bit-reproducible and one run on 24 scenes spreads by +-0.05 on its own
+    r = A.run("tiny", steps=320, batch=8, n_train=64, n_val=64, curve_steps=10, repeats=2)
     assert r["gate"]["loss_curve_max_rel_dev_first_steps"] <= 1e-2, (r["curve_sgd"], r["gate"])
     assert r["oracle"]["map50"] > 0.3 and r["hip_f32"]["map50"] > 0.3, (r["oracle"]["map50"], r["hip_f32"]["map50"])      # both learned
     assert r["gate"]["map50_abs_diff_f32_vs_oracle"] <= 0.1, r["gate"]

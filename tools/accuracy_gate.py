@@ -45,7 +45,7 @@ def usable_cpus():
     return n
 
 
-def run(model="tiny", steps=300, oracle_steps=None, opt="auto", batch=16, n_train=64, n_val=32, curve_steps=12, dev="cuda"):
+def run(model="tiny", steps=300, oracle_steps=None, opt="auto", batch=16, n_train=64, n_val=32, curve_steps=12, dev="cuda", repeats=1):
     torch.set_num_threads(usable_cpus())        # a GPU box shows every core of the host but grants one GPU's share: do not oversubscribe
     from sy11.data.spectrogram import SpectrogramProducer
     from sy11.engine.trainer import DetectionTrainer
@@ -69,7 +69,9 @@ def run(model="tiny", steps=300, oracle_steps=None, opt="auto", batch=16, n_trai
             yield {"img": img_va[lo:lo + batch], **{k: v.to(dev) for k, v in b.items()}}
 
     # the scale-`t` model has 4-channel bottlenecks: below the 16-byte vectors of the 16-bit kernels, f32 only
-    for tag, amp in ((("hip_f32", False),) if model == "tiny" else (("hip_f32", False), ("hip_f16", True))):
+    # HIP training is not bit-reproducible (f32 atomics): with `repeats` > 1 the gate compares the MEAN mAP of that many runs
+    legs = (("hip_f32", False),) if model == "tiny" else (("hip_f32", False), ("hip_f16", True))
+    for tag, amp in [(t, a_) for t, a_ in legs for _ in range(repeats)]:
         m = mk()
         m.load_state_dict(sd0)
         tr = DetectionTrainer(m, batch_size=batch, device=dev, graphs=True,
@@ -86,9 +88,12 @@ def run(model="tiny", steps=300, oracle_steps=None, opt="auto", batch=16, n_trai
         metrics = DetectionValidator(tr.ema.ema, device=dev, half=False)(tr.ema.ema, val_batches())
         if tag == "hip_f32":
             sd_trained = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
-        res[tag] = {"losses": [round(l, 4) for l in losses], "map50": float(metrics.get("metrics/mAP50(B)", 0.0)),
-                    "map": float(metrics.get("metrics/mAP50-95(B)", 0.0))}
-        log(f"{tag}: mAP@0.5 {res[tag]['map50']:.4f}  mAP@0.5:0.95 {res[tag]['map']:.4f}")
+        m50, m5095 = float(metrics.get("metrics/mAP50(B)", 0.0)), float(metrics.get("metrics/mAP50-95(B)", 0.0))
+        prev = res.get(tag, {"runs": []})
+        runs = prev["runs"] + [{"map50": m50, "map": m5095}]
+        res[tag] = {"losses": [round(l, 4) for l in losses], "runs": runs, "map50": sum(r_["map50"] for r_ in runs) / len(runs),
+                    "map": sum(r_["map"] for r_ in runs) / len(runs)}
+        log(f"{tag}: mAP@0.5 {m50:.4f}  mAP@0.5:0.95 {m5095:.4f}")
         del tr, m
     t0 = time.time()
     st, ol = TR.train({k: v.cpu() for k, v in sd0.items()}, layers, 2, img_tr.cpu(), tuple(lab_tr), batch, oracle_steps, lr=lr, momentum=mom,
