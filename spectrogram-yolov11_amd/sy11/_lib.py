@@ -152,7 +152,9 @@ def call(name: str, *args):
     e0.record()
     check(getattr(load(), name)(*args), name)
     e1.record()
+    global PROFILE_META
     PROFILE.append((name, e0, e1, PROFILE_META))
+    PROFILE_META = None                                   # meta belongs to exactly one call
 
 
 def set_option(name: str, value: int):

@@ -97,6 +97,8 @@ class Act:
 # Off by default: measured on MI355X (r01, 3 A/B pairs) the fork/join dependency costs ~10 us per layer inside the captured
 # graph and the overlap does not pay it back (26.55 ms vs 27.05 ms per step) — the kernels already fill every CU.
 _SIDE_WGRAD = os.environ.get("SY11_WGRAD_STREAM", "0") != "0"
+# > 1: batch that many filter-gradient launches per fork (one cross-stream edge per batch instead of one per layer)
+_SIDE_BATCH = max(int(os.environ.get("SY11_WGRAD_STREAM", "0") or 0), 1)
 _SIDE_STREAMS = {}
 
 
@@ -144,13 +146,25 @@ class Ctx:
             return
         if self.side is None:
             self.side = _side_stream(self.device)
+            self.side_queue = []
+        self.side_queue.append(fn)
+        self.side_refs.append(keep)
+        if len(self.side_queue) >= _SIDE_BATCH:
+            self.flush_side()
+
+    def flush_side(self):
+        """Fork: everything queued so far runs on the side stream, ordered after what the current stream has issued."""
+        if self.side is None or not self.side_queue:
+            return
         self.side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.side):
-            fn()
-        self.side_refs.append(keep)
+            for fn in self.side_queue:
+                fn()
+        self.side_queue = []
 
     def join_side(self):
         if self.side is not None and self.side_refs:
+            self.flush_side()
             torch.cuda.current_stream(self.device).wait_stream(self.side)
             self.side_refs.clear()
 

@@ -183,13 +183,23 @@ def _mc(t):
 
 def bn_finalize(count, ssum, ssq, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift):
     slots = ssum.shape[0] if ssum.dim() == 2 else 1
+    if _lib.PROFILE is not None:
+        _lib.PROFILE_META = {"flops": 0.0, "bytes": float(gamma.numel() * 4 * (2 * slots + 8)), "desc": f"bn_finalize {gamma.numel()}"}
     call("sy11_bn_finalize", gamma.numel(), slots, float(count), _p(ssum), _p(ssq), _p(gamma), _p(beta), eps, momentum,
          _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift), _stream())
+
+
+def _stream_meta(what, M, Cn, *tensors):
+    """Algorithmic bytes of a streaming pass (bench.py's roofline leg): every operand read or written once."""
+    if _lib.PROFILE is not None:
+        _lib.PROFILE_META = {"flops": 0.0, "bytes": float(sum(M * Cn * t.element_size() for t in tensors if t is not None)),
+                             "desc": f"{what} {M}x{Cn}"}
 
 
 def bn_act_fwd(y, scale, shift, z, silu=True, res=None):
     _need_gpu(y, z, res)
     M, Cn = _mc(y)
+    _stream_meta("bn_act_fwd", M, Cn, y, z, res)
     call("sy11_bn_act_fwd", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(scale), _p(shift), int(silu), _p(res),
          view_ld(res) if res is not None else 0, _p(z), view_ld(z), _stream())
     return z
@@ -197,6 +207,7 @@ def bn_act_fwd(y, scale, shift, z, silu=True, res=None):
 
 def bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, silu, sum_g, sum_gx):
     M, Cn = _mc(y)
+    _stream_meta("bn_bwd_reduce", M, Cn, y, dz)
     slots = sum_g.shape[0] if sum_g.dim() == 2 else 1
     call("sy11_bn_act_bwd_reduce", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
          _p(scale), _p(shift), int(silu), _p(sum_g), _p(sum_gx), slots, _stream())
@@ -204,6 +215,7 @@ def bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, silu, sum_g, sum_gx):
 
 def bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, dy, dgamma, dbeta):
     M, Cn = _mc(y)
+    _stream_meta("bn_bwd_apply", M, Cn, y, dz, dy)
     slots = sum_g.shape[0] if sum_g.dim() == 2 else 1
     call("sy11_bn_act_bwd_apply", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
          _p(scale), _p(shift), _p(gamma), int(silu), _p(sum_g), _p(sum_gx), slots, _p(dy), view_ld(dy), _p(dgamma),
