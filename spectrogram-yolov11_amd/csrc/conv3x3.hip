@@ -362,3 +362,215 @@ int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn_code, hipStream_t st) {
   SY11_LAUNCH_CHECK("halo3x3");
   return SY11_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ stride-2 input gradient
+// dx of a 3x3 / stride 2 / pad 1 convolution, all four output-parity classes in ONE pass over dy.
+//
+// The generic path (igemm.hip) runs one launch per parity class of dx (1, 2, 2 and 4 taps): dy is read four times, every class writes
+// every other pixel of every other row (half cache lines), and each class is a short-K GEMM.  Here a workgroup owns TH x TW QUADS
+// (2x2 blocks of dx pixels = TH x TW positions of the dy grid): the dy patch it needs — (TH+1) x (TW+1) pixels — is loaded once per
+// 32-channel slab, the nine taps run as nine MFMA stages into FOUR accumulator sets (one per parity class: a tap belongs to exactly
+// one class and reads the patch at a row offset in {0,1} x {0,1}), and the epilogue interleaves the four classes in LDS so that dx is
+// written as whole contiguous pixel rows of the 2TH x 2TW block.  Same machinery as halo3x3_kernel otherwise.
+//   class (py, px) of dx pixel (2Y+py, 2X+px):  py = 0: filter row r = 1 (dy row Y);  py = 1: r = 0 (dy row Y+1) and r = 2 (dy row Y).
+template <int TH, int TW, int BN, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void halo_dgrad_s2_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y) {
+  typedef _Float16 T;
+  constexpr int BM = 128, KB = 64, RPI = 16, WM = 4, NI = BN / 32;
+  constexpr int PH = TH + 1, PW = TW + 1, PR = PH * PW, NIA = (PR + RPI - 1) / RPI;
+  constexpr int NAW = (NIA + 1) / 2, A_BYTES = 2 * NAW * RPI * KB, CH = (NAW + 5) / 6;
+  constexpr int NSTB = 4, B_BYTES = BN * KB, BPW = (BN / RPI + 1) / 2;
+  constexpr int NVALID = TH * TW;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int LOOP_BYTES = 2 * A_BYTES + NSTB * B_BYTES, OUT_BYTES = 4 * BM * BN * 2;
+  static_assert(NVALID <= BM && BN % 32 == 0, "tile layout");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LOOP_BYTES > OUT_BYTES ? LOOP_BYTES : OUT_BYTES];
+  // stage t -> (parity class, patch row offset, patch column offset, filter tap r*3+s)
+  constexpr int CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+  constexpr int AY[9] = {0, 0, 0, 1, 0, 1, 1, 0, 0};
+  constexpr int AX[9] = {0, 1, 0, 0, 0, 1, 0, 1, 0};
+  constexpr int WT[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool is_b = wave_u < 2;
+  const int wr = wave_u & 1;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % a.tiles_n;
+  int tq = bid / a.tiles_n;
+  const int tile_x = tq % tiles_x;
+  tq /= tiles_x;
+  const int tile_y = tq % tiles_y;
+  const int img = tq / tiles_y;
+  const int Y0 = tile_y * TH, X0 = tile_x * TW, bn0 = tile_n * BN;
+  // here: a.x = dy (B, a.IH, a.IW, a.C) with a.IH/IW = the conv's OUTPUT size; a.y = dx (B, a.OHF, a.OWF, a.N) = the conv's input
+  const h_rsrc_t xr = h_make_rsrc(a.x, a.x_bytes), wr_ = h_make_rsrc(a.w, a.w_bytes);
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned sB_base = smem_base + 2 * A_BYTES;
+  const int lrow = lane >> 2, lphys = lane & 3;
+
+  int b_off[BPW], a_off[NAW];
+#pragma unroll
+  for (int k = 0; k < BPW; ++k) {
+    const int rl = (wr * BPW + k) * RPI + lrow, n = bn0 + rl;
+    b_off[k] = (is_b && rl < BN && n < a.N) ? n * a.wK * 2 + (lphys ^ ((rl >> 2) & 3)) * 16 : (int)OOB;
+  }
+#pragma unroll
+  for (int k = 0; k < NAW; ++k) {
+    const int j = wr + 2 * k, p = j * RPI + lrow;
+    const int py = p / PW, px = p - py * PW;
+    const int oy = Y0 + py, ox = X0 + px;
+    const bool ok = !is_b && j < NIA && p < PR && oy < a.IH && ox < a.IW;
+    a_off[k] = ok ? ((img * a.IH + oy) * a.IW + ox) * a.x_ld * 2 + (lphys ^ ((p >> 2) & 3)) * 16 : (int)OOB;
+  }
+  const int frow = lane & 31, fh = lane >> 5;
+  const int r0 = wave * 32 + frow;
+  const int arow0 = r0 < NVALID ? (r0 / TW) * PW + (r0 % TW) : 0;
+  int fb_off[NI][2];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int r = j * 32 + frow;
+      fb_off[j][g] = r * KB + (((2 * g + fh) ^ ((r >> 2) & 3)) << 4);
+    }
+  f32x16 acc[4][NI];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[c][j][e] = 0.f;
+
+  const int nslab = a.C >> 5, nstage = nslab * 9;
+  auto issue_b = [&](int bufq, int tap, int slab) {
+    const unsigned dst = sB_base + bufq * B_BYTES + (wr * BPW) * (RPI * KB);
+    const int ko = (tap * a.C + slab * 32) * 2;
+#pragma unroll
+    for (int k = 0; k < BPW; ++k) h_dma16(dst + k * (RPI * KB), b_off[k] >= 0 ? (unsigned)(b_off[k] + ko) : OOB, wr_);
+  };
+  auto issue_a = [&](int k0, int k1, int slab) {
+    const unsigned dst = smem_base + (slab & 1) * A_BYTES;
+#pragma unroll
+    for (int k = 0; k < NAW; ++k)
+      if (k >= k0 && k < k1) h_dma16(dst + (wr + 2 * k) * (RPI * KB), a_off[k] >= 0 ? (unsigned)(a_off[k] + slab * KB) : OOB, xr);
+  };
+  if (is_b) {
+#pragma unroll
+    for (int q = 0; q < NSTB - 1; ++q)
+      if (q < nstage) issue_b(q & 3, WT[q], 0);
+  } else {
+    issue_a(0, NAW, 0);
+  }
+  for (int slab = 0; slab < nslab; ++slab) {
+    const unsigned char* sAc = smem + (slab & 1) * A_BYTES;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int q = slab * 9 + t;
+      if (is_b) {
+        const int later = nstage - 1 - q;
+        if (later >= 2) h_wait_vm<2 * BPW>();
+        else if (later == 1) h_wait_vm<BPW>();
+        else h_wait_vm<0>();
+      } else if (t == 0) {
+        h_wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (is_b) {
+        const int t3 = (t + 3) % 9, s3 = slab + (t + 3) / 9;
+        if (q + 3 < nstage) issue_b((s3 + t3) & 3, WT[t3], s3);
+      } else if (t < 6 && slab + 1 < nslab) {
+        issue_a(t * CH, (t + 1) * CH < NAW ? (t + 1) * CH : NAW, slab + 1);
+      }
+      const unsigned char* sBc = smem + 2 * A_BYTES + ((slab + t) & 3) * B_BYTES;
+      const int row = arow0 + AY[t] * PW + AX[t];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint4 fa = *(const uint4*)(sAc + row * KB + (((2 * g + fh) ^ ((row >> 2) & 3)) << 4));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const uint4 fb = *(const uint4*)(sBc + fb_off[j][g]);
+          h_mma(fa, fb, acc[CLS[t]][j]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- epilogue: the four classes interleaved into a [2TH][2TW][BN] image in LDS, then whole pixel rows to dx
+  constexpr bool accum = EPI & 8;
+  constexpr int ROWB = BN * 2, CPR = ROWB / 16, DW = 2 * TW;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;           // quad index
+      if (rl < NVALID) {
+        const int ty = rl / TW, tx = rl - ty * TW;
+        const int prow = (2 * ty + (c >> 1)) * DW + 2 * tx + (c & 1);        // pixel inside the 2TH x 2TW block
+#pragma unroll
+        for (int j = 0; j < NI; ++j) *(T*)(smem + prow * ROWB + (j * 32 + frow) * 2) = (T)acc[c][j][e];
+      }
+    }
+  __syncthreads();
+  for (int idx = tid; idx < 4 * NVALID * CPR; idx += 256) {
+    const int prow = idx / CPR, ch = idx - prow * CPR;
+    const int yy = prow / DW, xx = prow - yy * DW;
+    const int iy = 2 * Y0 + yy, ix = 2 * X0 + xx, n = bn0 + ch * 8;
+    if (iy >= a.OHF || ix >= a.OWF || n >= a.N || a.debug == 5) continue;
+    uint4 v = *(const uint4*)(smem + prow * ROWB + ch * 16);
+    unsigned char* gp = (unsigned char*)a.y + (((long)(img * a.OHF + iy) * a.OWF + ix) * a.y_ld + n) * 2;
+    if (accum) {
+      const uint4 o = *(const uint4*)gp;
+      f16x8 x = __builtin_bit_cast(f16x8, v), y = __builtin_bit_cast(f16x8, o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = (_Float16)((float)x[k] + (float)y[k]);
+      v = __builtin_bit_cast(uint4, x);
+    }
+    *(uint4*)gp = v;
+  }
+}
+
+// a: x = dy, IH/IW = dy's (the conv's output) size, C = dy channels, w = tap-transposed filter [Cin][9][C], wK = 9*C,
+//    y = dx, OHF/OWF = dx's (the conv's input) size, N = Cin, flags & ACCUM.  Legal: f16, C % 32 == 0, N % 8 == 0, tile table.
+bool sy11_halo_dgrad_s2_legal(const IgemmArgs& a) {
+  int th, tw;
+  if (a.C % 32 || a.N % 8 || a.wK != 9 * a.C || !halo_tile(a.IW, a.IH, 0, &th, &tw)) return false;
+  if (((uintptr_t)a.y & 15) || (a.y_ld * 2) % 16 || ((uintptr_t)a.x & 15) || (a.x_ld * 2) % 16) return false;
+  return (a.OHF == 2 * a.IH || a.OHF == 2 * a.IH - 1) && (a.OWF == 2 * a.IW || a.OWF == 2 * a.IW - 1);
+}
+
+template <int TH, int TW>
+static void halo_dgrad_s2_tile(const IgemmArgs& a, int bn, bool accum, dim3 grid, hipStream_t st, int tx, int ty) {
+  dim3 block(256);
+  if (bn == 64) {
+    if (accum) hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 64, 8>), grid, block, 0, st, a, tx, ty);
+    else hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 64, 0>), grid, block, 0, st, a, tx, ty);
+  } else {
+    if (accum) hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 32, 8>), grid, block, 0, st, a, tx, ty);
+    else hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 32, 0>), grid, block, 0, st, a, tx, ty);
+  }
+}
+
+int sy11_halo_dgrad_s2_launch(const IgemmArgs& a_in, hipStream_t st) {
+  if (!sy11_halo_dgrad_s2_legal(a_in)) SY11_FAIL(SY11_EUNSUPPORTED, "halo_dgrad_s2: problem not covered");
+  IgemmArgs a = a_in;
+  int th, tw;
+  halo_tile(a.IW, a.IH, 0, &th, &tw);
+  const int bn = a.N > 32 ? 64 : 32;
+  const int B = a.M;                                  // the caller passes the batch size in M
+  const int tx = cdiv(a.IW, tw), ty = cdiv(a.IH, th);
+  a.tiles_n = cdiv(a.N, bn);
+  const long nwg = (long)B * tx * ty * a.tiles_n;
+  if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "halo_dgrad_s2: bad grid %ld", nwg);
+  dim3 grid((unsigned)nwg);
+  const bool accum = a.flags & SY11_EPI_ACCUM;
+  if (tw == 16) halo_dgrad_s2_tile<8, 16>(a, bn, accum, grid, st, tx, ty);
+  else if (tw == 20) halo_dgrad_s2_tile<6, 20>(a, bn, accum, grid, st, tx, ty);
+  else halo_dgrad_s2_tile<3, 40>(a, bn, accum, grid, st, tx, ty);
+  SY11_LAUNCH_CHECK("halo_dgrad_s2");
+  return SY11_OK;
+}

@@ -807,6 +807,25 @@ extern "C" int sy11_conv2d_dgrad(const sy11_conv_desc* d, const void* dy, int32_
   SY11_REQUIRE(wt && dx, "conv2d_dgrad: null wt/dx");
   SY11_REQUIRE(((uintptr_t)wt & 15) == 0, "conv2d_dgrad: wt not 16-byte aligned");
   SY11_REQUIRE(!(d->flags & (SY11_EPI_SILU | SY11_EPI_OUT_F32)), "conv2d_dgrad: only SY11_EPI_ACCUM is meaningful");
+  // 3x3 / stride 2 / pad 1 in f16: all four parity classes in ONE pass over dy (conv3x3.hip halo_dgrad_s2_kernel), unless switched off
+  if (d->dtype == SY11_F16 && d->KH == 3 && d->KW == 3 && d->SH == 2 && d->SW == 2 && d->PH == 1 && d->PW == 1 && d->DH == 1 && d->DW == 1 &&
+      sy11_opt(OPT_IGEMM_CFG) < 0 && (sy11_opt(OPT_DGRAD_S2_HALO) == 2 || (sy11_opt(OPT_DGRAD_S2_HALO) == 1 && d->C <= 64))) {
+    // default (1): only where dx has <= 64 channels = ONE channel tile per dy patch — 413 -> 170 us on 320x320x32 <- 160x160x64; with
+    // 128 / 256 dx channels the 64-wide tiles re-read the patch 2-4x and one workgroup per CU loses to the four igemm launches
+    // (284 -> 315, 236 -> 299 us).  2 = always (tests).
+    IgemmArgs a{};
+    a.x = dy; a.w = wt; a.y = dx;
+    a.C = d->N; a.wK = 9 * d->N; a.N = d->C; a.K = 9 * d->N; a.T = 9;
+    a.x_ld = dy_ld; a.y_ld = d->x_ld;
+    a.IH = d->OH; a.IW = d->OW; a.OHF = d->IH; a.OWF = d->IW;
+    a.M = d->B;
+    a.flags = d->flags & SY11_EPI_ACCUM;
+    const long xb = (((long)d->B * d->OH * d->OW - 1) * dy_ld + d->N) * 2, wb = (long)d->C * 9 * d->N * 2;
+    if (xb < (1L << 31) && wb < (1L << 31)) {
+      a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+      if (sy11_halo_dgrad_s2_legal(a)) return sy11_halo_dgrad_s2_launch(a, st);
+    }
+  }
   // one launch per output-parity class (ph, pw): pixels i = SH*i' + ph use only taps with (ph + PH - r*DH) % SH == 0
   for (int ph = 0; ph < d->SH; ++ph)
     for (int pw = 0; pw < d->SW; ++pw) {

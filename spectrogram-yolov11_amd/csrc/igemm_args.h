@@ -36,3 +36,6 @@ struct IgemmArgs {
 // halo-tiled 3x3 kernel (conv3x3.hip): bn = channels per workgroup (128 / 64 / 32), + 1000 for the 256-pixel tiles; returns SY11_OK or a negative status
 bool sy11_halo3x3_legal(const IgemmArgs& a, int bn);
 int sy11_halo3x3_launch(const IgemmArgs& a, int bn, hipStream_t st);
+// stride-2 3x3 input gradient, all four parity classes in one pass (conv3x3.hip); see the argument convention there
+bool sy11_halo_dgrad_s2_legal(const IgemmArgs& a);
+int sy11_halo_dgrad_s2_launch(const IgemmArgs& a, hipStream_t st);

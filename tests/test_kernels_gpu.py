@@ -177,6 +177,38 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
         _lib.set_option("tune", tune0)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 32, 32, 96), (1, 32, 80, 80, 64), (1, 32, 31, 39, 64), (2, 256, 40, 40, 128), (3, 128, 32, 48, 32)])
+def test_stride2_input_gradient_all_parities_in_one_pass(case):
+    """halo_dgrad_s2_kernel (conv3x3.hip): dx of a 3x3 / stride 2 / pad 1 conv, four parity classes from one dy patch, whole
+    pixel rows written — against the fp32 CPU gradient, plain and accumulating, and bit-for-bit-close to the four-launch igemm path."""
+    from sy11 import _lib
+    o = ops()
+    dtype = torch.float16
+    B, Cn, H, W, N = case
+    k, s, p = 3, 2, 1
+    OH, OW = o.conv_out_hw(H, W, k, s, p)
+    w = rnd(N, Cn, k, k, seed=22, scale=1.0 / math.sqrt(Cn * 9))
+    dy = rnd(B, N, OH, OW, seed=23)
+    wq, dyq = q(w, dtype), q(dy, dtype)
+    dyv = nhwc(dy, dtype, 16)
+    wk = wq.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wt = o.weight_transpose(wk)
+    ref_dx = torch.nn.grad.conv2d_input((B, Cn, H, W), wq, dyq, s, p)
+    outs = []
+    try:
+        for flag in (2, 0):
+            _lib.set_option("dgrad_s2_halo", flag)
+            dx = torch.zeros(B, H, W, Cn + 8, dtype=dtype, device=DEV)[..., :Cn]          # ld > C
+            o.conv2d_dgrad(dyv, wt, dx, (B, OH, OW, N), k, s, p)
+            close(to_nchw(dx), ref_dx, dtype, f"dgrad s2 (halo {flag})")
+            o.conv2d_dgrad(dyv, wt, dx, (B, OH, OW, N), k, s, p, accumulate=True)
+            close(to_nchw(dx), 2 * ref_dx, dtype, f"dgrad s2 accumulate (halo {flag})", mult=2)
+            outs.append(to_nchw(dx))
+    finally:
+        _lib.set_option("dgrad_s2_halo", 1)
+    assert (outs[0] - outs[1]).abs().max().item() <= 4e-3 * ref_dx.abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("Cn,H,W", [(64, 8, 8), (24, 7, 5), (5, 6, 6), (256, 20, 20), (128, 13, 27), (512, 3, 12)])
 def test_depthwise_conv(Cn, H, W, dtype):

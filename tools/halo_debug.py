@@ -18,7 +18,11 @@ wt = ops.weight_transpose(w)
 _lib.set_option("tune", 0)
 outs = {}
 for c in (0, cfg):
-    _lib.set_option("igemm_cfg", c)
+    if mode == "dgrad2":                    # fused-parity stride-2 input gradient (conv3x3.hip) vs the four igemm launches
+        _lib.set_option("igemm_cfg", -1)
+        _lib.set_option("dgrad_s2_halo", 0 if c == 0 else 2)
+    else:
+        _lib.set_option("igemm_cfg", c)
     if mode == "fwd":
         y = torch.zeros(B, OH, OW, N, device="cuda", dtype=torch.float16)
         ops.conv2d_fwd(x, w, y, k, s, p)
