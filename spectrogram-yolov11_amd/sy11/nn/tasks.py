@@ -196,11 +196,19 @@ class DetectionModel(BaseModel):
             m.inplace = self.inplace
             # The reference discovers the strides with a train-mode dry run on zeros(1, ch, 256, 256) (tasks.py:359-367).
             # There is no CPU execution path here, so they are derived from the graph (product of conv strides /
-            # upsample factors along each Detect input) — same values; the dry run's side effect on the BN running
-            # buffers (one momentum-0.1 update from a zero image) is deliberately NOT reproduced.
+            # upsample factors along each Detect input) — same values.  The dry run's side effect is reproduced in closed
+            # form: on a zero image every bias-free conv yields zeros, every BatchNorm (beta = 0 at construction) sees batch
+            # mean 0 / variance 0 and maps to zeros again, so each of them takes ONE running-statistics update with the
+            # constructor's momentum 0.1: running_mean 0, running_var 0.9 * 1 + 0.1 * 0, num_batches_tracked 1 — checked
+            # against the reference's fresh models (yolo11n, the fusion variant: all 81 / 88 BatchNorms, r02).
             m.stride = torch.tensor(_graph_strides(self.model, self.save))
             self.stride = m.stride
             m.bias_init()
+            for mod in self.modules():
+                if type(mod) is nn.BatchNorm2d and mod.track_running_stats:
+                    mod.running_mean.zero_()
+                    mod.running_var.fill_(0.9)
+                    mod.num_batches_tracked.fill_(1)
         else:
             self.stride = torch.Tensor([32])
         initialize_weights(self)

@@ -28,6 +28,10 @@ def test_parse_model_matches_reference_inventory():
         assert m.save == [4, 6, 10, 13, 16, 19, 22]
         bn = m.model[0].bn
         assert bn.eps == 1e-3 and bn.momentum == 0.03                        # torch_utils.py:417-418
+        # constructor state of the reference (its stride dry run on a zero image, tasks.py:359-367): one momentum-0.1 update
+        bns = [b for b in m.modules() if type(b) is torch.nn.BatchNorm2d]
+        assert len(bns) == 81 and all(int(b.num_batches_tracked) == 1 and float(b.running_mean.abs().max()) == 0.0
+                                      and torch.equal(b.running_var, torch.full_like(b.running_var, 0.9)) for b in bns)
     det = m.model[-1]
     assert det.cv2[0][-1].bias.data.eq(1.0).all()                            # head.py:138
     assert abs(det.cv3[0][-1].bias.data[0].item() - np.log(5 / 80 / (640 / 8) ** 2)) < 1e-6
