@@ -7,7 +7,8 @@ the oracle cannot run these shapes in seconds, the identities below need no refe
   * BatchNorm + SiLU apply: per-channel mean / variance of the normalised tensor
   * the whole model: the training loss and gradients are invariant under a permutation of the batch (train-mode BN
     statistics are permutation invariant), and two replays of the captured graph on the same batch agree.
-The autotuner is active, so whatever tile configuration each layer gets on this GPU is what is checked."""
+The tile autotuner is off in the test suite (tests/conftest.py): the heuristic configurations — incl. the halo-tiled 3x3 kernel — are what is
+checked here; every configuration is forced on its own in test_kernels_gpu.py."""
 import math
 
 import pytest
@@ -152,3 +153,62 @@ def test_graph_replay_is_repeatable_full_size():
     # BN running statistics move, the training-mode loss does not depend on them: replays must agree with the eager steps
     # (f32 atomics in the statistics / gradient sums reorder between runs; nothing else may differ)
     assert max(losses) - min(losses) <= 3e-3 * abs(losses[0]), losses
+
+
+# ---- configs[4]: the fusion variant's own kernels at full size (yolo11s_fusion_sand3_new @ 640 x 640, batch 64)
+@pytest.mark.parametrize("H,C,N,k", [(160, 128, 128, 7), (80, 256, 128, 3)], ids=["layer11_k7_d2_g8", "layer13_k3_d2_g8"])
+def test_ddwconv_grouped_dilated_adjoint_full_size(H, C, N, k):
+    """DDWConv.conv1 = Conv(c1, c2, k, s=2, g=8, d=2) (conv.py:694-710; cfg yolo11_fusion_sand3_new.yaml:33-37) at batch 64:
+    <conv(x; w), dy> = <x, dgrad(dy; w)> = <w, wgrad(x, dy)> through the grouped / dilated paths; stride and dilation share a factor,
+    so half of the input pixels receive no tap: dgrad must leave them exactly zero."""
+    from sy11 import ops
+    B, s, d, g, dtype, tol = 64, 2, 2, 8, torch.float16, 4e-3
+    p = (d * (k - 1) + 1) // 2
+    OH, OW = ops.conv_out_hw(H, H, k, s, p, d)
+    gen = torch.Generator(device=DEV).manual_seed(H + k)
+    x = torch.randn(B, H, H, C, device=DEV, generator=gen).to(dtype)
+    w = (torch.randn(N, k, k, C // g, device=DEV, generator=gen) / math.sqrt(C // g * k * k)).to(dtype)
+    dy = torch.randn(B, OH, OW, N, device=DEV, generator=gen).to(dtype)
+    y = torch.empty(B, OH, OW, N, device=DEV, dtype=dtype)
+    dx = torch.zeros_like(x)
+    dw = torch.zeros(N, k, k, C // g, device=DEV)
+    ops.conv2d_fwd(x, w, y, k, s, p, d, g)
+    assert ops.dgrad_leaves_holes(k, s, p, d)
+    ops.conv2d_dgrad(dy, ops.weight_transpose(w, g), dx, (B, OH, OW, N), k, s, p, d, g, accumulate=True)
+    ops.conv2d_wgrad(x, dy, dw, k, s, p, d, g)
+    a, b, c = dot(y, dy), dot(x, dx), dot(w, dw)
+    scale = math.sqrt(B * OH * OW * N) * (y.float().std().item() + 1e-6)
+    assert abs(a - b) <= tol * scale * 8 and abs(a - c) <= tol * scale * 8, (a, b, c, scale)
+    # taps land on input pixels of one parity only (iy = 2*oy - p + 2*r): the other rows / columns stay exactly zero
+    par = (p % 2)
+    assert float(dx[:, (1 - par)::2].abs().max()) == 0.0 and float(dx[:, :, (1 - par)::2].abs().max()) == 0.0
+    assert float(dx[:, par::2, par::2].abs().max()) > 0.0
+
+
+def test_fusion_eschannel_directional_derivative_full_size():
+    """Fusion([128, 128, 128], 'ESChannel') (conv.py:2087-2127) on three 64 x 128 x 80 x 80 maps, f32: the backward kernels
+    (fusion_bwd_reduce / sab_map_bwd / gct_gate_bwd / fusion_bwd_apply) against a central finite difference of L = 0.5 * sum(out^2) along a random
+    direction — (L(x + e v) - L(x - e v)) / 2e = sum_i <dL/dx_i, v_i> — and batch-permutation equivariance of the forward."""
+    from sy11.nn.modules import Fusion
+    torch.manual_seed(0)
+    m = Fusion([128, 128, 128], "ESChannel").to(DEV).train()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.add_(0.2 * torch.randn_like(p_))
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    xs = [torch.randn(64, 128, 80, 80, device=DEV, generator=gen).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(3)]
+    vs = [torch.randn(64, 128, 80, 80, device=DEV, generator=gen).contiguous(memory_format=torch.channels_last) for _ in range(3)]
+    out = m(xs)
+    (0.5 * out * out).sum().backward()                         # L = 0.5 sum out^2: a coherent signal (a random cotangent drowns it in noise)
+    lhs = sum(dot(x.grad, v) for x, v in zip(xs, vs))
+    eps = 1e-2
+    with torch.no_grad():
+        fp = m([(x + eps * v) for x, v in zip(xs, vs)])
+        fm = m([(x - eps * v) for x, v in zip(xs, vs)])
+        rhs = (0.5 * dot(fp, fp) - 0.5 * dot(fm, fm)) / (2 * eps)
+        perm = torch.randperm(64, device=DEV, generator=gen)
+        outp = m([x[perm].contiguous(memory_format=torch.channels_last) for x in xs])
+    # central difference: O(eps^2) truncation plus the kinks of the channel-max inside the spatial attention (a few pixels change
+    # their arg-max along the direction)
+    assert abs(lhs - rhs) <= 2e-2 * abs(rhs), (lhs, rhs)
+    assert (outp - out[perm]).abs().max().item() <= 1e-4 * out.abs().max().item()
