@@ -243,21 +243,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void h
       }
     }
   __syncthreads();
-  for (int idx = tid; idx < NVALID * CPR; idx += 256) {
-    const int rl = idx / CPR, ch = idx - rl * CPR;
-    const int ty = rl / TW, tx = rl - ty * TW;
-    const int oy = oy0 + ty, ox = ox0 + tx, n = bn0 + ch * 8;
-    if (oy >= a.OH || ox >= a.OW || n >= a.N || a.debug == 5) continue;      // debug 5 = tuner dry run of an accumulating epilogue
-    uint4 v = *(const uint4*)(smem + rl * ROWB + ch * 16);
-    unsigned char* gp = (unsigned char*)a.y + (((long)(img * a.OH + oy) * a.OW + ox) * a.y_ld + n) * 2;
-    if (accum) {
-      const uint4 o = *(const uint4*)gp;
-      f16x8 x = __builtin_bit_cast(f16x8, v), y = __builtin_bit_cast(f16x8, o);
+  // four chunks per thread per trip: an accumulating epilogue reads its four y chunks before the first add (one round trip, not four)
+  constexpr int U = 4;
+  for (int base = tid; base < NVALID * CPR; base += 256 * U) {
+    unsigned char* gp[U];
+    uint4 o[U];
+    int lofs[U];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) x[k] = (_Float16)((float)x[k] + (float)y[k]);
-      v = __builtin_bit_cast(uint4, x);
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256;
+      const int rl = idx / CPR, ch = idx - rl * CPR;
+      const int ty = rl / TW, tx = rl - ty * TW;
+      const int oy = oy0 + ty, ox = ox0 + tx, n = bn0 + ch * 8;
+      const bool ok = idx < NVALID * CPR && oy < a.OH && ox < a.OW && n < a.N && a.debug != 5;      // debug 5 = tuner dry run of an accumulating epilogue
+      gp[u] = ok ? (unsigned char*)a.y + (((long)(img * a.OH + oy) * a.OW + ox) * a.y_ld + n) * 2 : nullptr;
+      lofs[u] = rl * ROWB + ch * 16;
+      if (accum && ok) o[u] = *(const uint4*)gp[u];
     }
-    *(uint4*)gp = v;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!gp[u]) continue;
+      uint4 v = *(const uint4*)(smem + lofs[u]);
+      if (accum) {
+        f16x8 x = __builtin_bit_cast(f16x8, v), y = __builtin_bit_cast(f16x8, o[u]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (_Float16)((float)x[k] + (float)y[k]);
+        v = __builtin_bit_cast(uint4, x);
+      }
+      *(uint4*)gp[u] = v;
+    }
   }
   if (do_stats) {
 #pragma unroll
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void h
   constexpr int NSTB = 4, B_BYTES = BN * KB, BPW = (BN / RPI + 1) / 2;
   constexpr int NVALID = TH * TW;
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int LOOP_BYTES = 2 * A_BYTES + NSTB * B_BYTES, OUT_BYTES = 4 * BM * BN * 2;
+  constexpr int LOOP_BYTES = 2 * A_BYTES + NSTB * B_BYTES, OUT_BYTES = 2 * BM * BN * 2;   // epilogue: one dx row parity at a time
   static_assert(NVALID <= BM && BN % 32 == 0, "tile layout");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LOOP_BYTES > OUT_BYTES ? LOOP_BYTES : OUT_BYTES];
   // stage t -> (parity class, patch row offset, patch column offset, filter tap r*3+s)
@@ -500,37 +514,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void h
     }
   }
   __syncthreads();
-  // ---- epilogue: the four classes interleaved into a [2TH][2TW][BN] image in LDS, then whole pixel rows to dx
+  // ---- epilogue, one dx row parity (py) at a time: the two classes (py, 0) and (py, 1) interleaved into a [TH][2TW][BN] image in
+  // LDS = the dx rows 2*(Y0+ty)+py of the block, then written as whole contiguous pixel rows
   constexpr bool accum = EPI & 8;
   constexpr int ROWB = BN * 2, CPR = ROWB / 16, DW = 2 * TW;
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int py = 0; py < 2; ++py) {
+    if (py) __syncthreads();                          // the previous parity's rows have been read out
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int rl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;           // quad index
-      if (rl < NVALID) {
-        const int ty = rl / TW, tx = rl - ty * TW;
-        const int prow = (2 * ty + (c >> 1)) * DW + 2 * tx + (c & 1);        // pixel inside the 2TH x 2TW block
+    for (int px = 0; px < 2; ++px)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) *(T*)(smem + prow * ROWB + (j * 32 + frow) * 2) = (T)acc[c][j][e];
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;         // quad index
+        if (rl < NVALID) {
+          const int ty = rl / TW, tx = rl - ty * TW;
+          const int prow = ty * DW + 2 * tx + px;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) *(T*)(smem + prow * ROWB + (j * 32 + frow) * 2) = (T)acc[2 * py + px][j][e];
+        }
+      }
+    __syncthreads();
+    constexpr int U = 4;                               // as in halo3x3_kernel: the reads of an accumulating epilogue go out four at a time
+    for (int base = tid; base < 2 * NVALID * CPR; base += 256 * U) {
+      unsigned char* gp[U];
+      uint4 o[U];
+      int lofs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * 256;
+        const int prow = idx / CPR, ch = idx - prow * CPR;
+        const int ty = prow / DW, xx = prow - ty * DW;
+        const int iy = 2 * (Y0 + ty) + py, ix = 2 * X0 + xx, n = bn0 + ch * 8;
+        const bool ok = idx < 2 * NVALID * CPR && iy < a.OHF && ix < a.OWF && n < a.N && a.debug != 5;
+        gp[u] = ok ? (unsigned char*)a.y + (((long)(img * a.OHF + iy) * a.OWF + ix) * a.y_ld + n) * 2 : nullptr;
+        lofs[u] = prow * ROWB + ch * 16;
+        if (accum && ok) o[u] = *(const uint4*)gp[u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!gp[u]) continue;
+        uint4 v = *(const uint4*)(smem + lofs[u]);
+        if (accum) {
+          f16x8 x = __builtin_bit_cast(f16x8, v), y = __builtin_bit_cast(f16x8, o[u]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = (_Float16)((float)x[k] + (float)y[k]);
+          v = __builtin_bit_cast(uint4, x);
+        }
+        *(uint4*)gp[u] = v;
       }
     }
-  __syncthreads();
-  for (int idx = tid; idx < 4 * NVALID * CPR; idx += 256) {
-    const int prow = idx / CPR, ch = idx - prow * CPR;
-    const int yy = prow / DW, xx = prow - yy * DW;
-    const int iy = 2 * Y0 + yy, ix = 2 * X0 + xx, n = bn0 + ch * 8;
-    if (iy >= a.OHF || ix >= a.OWF || n >= a.N || a.debug == 5) continue;
-    uint4 v = *(const uint4*)(smem + prow * ROWB + ch * 16);
-    unsigned char* gp = (unsigned char*)a.y + (((long)(img * a.OHF + iy) * a.OWF + ix) * a.y_ld + n) * 2;
-    if (accum) {
-      const uint4 o = *(const uint4*)gp;
-      f16x8 x = __builtin_bit_cast(f16x8, v), y = __builtin_bit_cast(f16x8, o);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) x[k] = (_Float16)((float)x[k] + (float)y[k]);
-      v = __builtin_bit_cast(uint4, x);
-    }
-    *(uint4*)gp = v;
   }
 }
 
@@ -546,7 +578,10 @@ bool sy11_halo_dgrad_s2_legal(const IgemmArgs& a) {
 template <int TH, int TW>
 static void halo_dgrad_s2_tile(const IgemmArgs& a, int bn, bool accum, dim3 grid, hipStream_t st, int tx, int ty) {
   dim3 block(256);
-  if (bn == 64) {
+  if (bn == 128) {
+    if (accum) hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 128, 8>), grid, block, 0, st, a, tx, ty);
+    else hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 128, 0>), grid, block, 0, st, a, tx, ty);
+  } else if (bn == 64) {
     if (accum) hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 64, 8>), grid, block, 0, st, a, tx, ty);
     else hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 64, 0>), grid, block, 0, st, a, tx, ty);
   } else {
@@ -560,7 +595,7 @@ int sy11_halo_dgrad_s2_launch(const IgemmArgs& a_in, hipStream_t st) {
   IgemmArgs a = a_in;
   int th, tw;
   halo_tile(a.IW, a.IH, 0, &th, &tw);
-  const int bn = a.N > 32 ? 64 : 32;
+  const int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   const int B = a.M;                                  // the caller passes the batch size in M
   const int tx = cdiv(a.IW, tw), ty = cdiv(a.IH, th);
   a.tiles_n = cdiv(a.N, bn);

@@ -18,7 +18,7 @@ extern "C" const char* sy11_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------ run-time options
 static int g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
-static const char* const kOptName[OPT_COUNT] = {"tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder", "igemm_deep", "igemm_bpol", "dgrad_s2_halo"};
+static const char* const kOptName[OPT_COUNT] = {"tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder", "igemm_deep", "igemm_bpol", "dgrad_s2_halo", "row_map"};
 static void opt_init() {
   auto env = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
   g_opt[OPT_TUNE] = env("SY11_TUNE", 1) != 0;
@@ -29,6 +29,7 @@ static void opt_init() {
   g_opt[OPT_IGEMM_DEEP] = env("SY11_IGEMM_DEEP", 0);
   g_opt[OPT_IGEMM_BPOL] = env("SY11_IGEMM_BPOL", 0);
   g_opt[OPT_DGRAD_S2_HALO] = env("SY11_DGRAD_S2_HALO", 1);
+  g_opt[OPT_ROW_MAP] = env("SY11_ROW_MAP", 1);
 }
 int sy11_opt(int which) {
   std::call_once(g_opt_once, opt_init);
@@ -42,7 +43,7 @@ static int opt_index(const char* name) {
 }
 extern "C" int sy11_set_option(const char* name, int32_t value) {
   const int i = opt_index(name);
-  SY11_REQUIRE(i >= 0, "set_option: unknown option '%s' (tune, tune_log, igemm_cfg, wgrad_cfg, igemm_korder, igemm_deep, igemm_bpol, dgrad_s2_halo)", name ? name : "(null)");
+  SY11_REQUIRE(i >= 0, "set_option: unknown option '%s' (tune, tune_log, igemm_cfg, wgrad_cfg, igemm_korder, igemm_deep, igemm_bpol, dgrad_s2_halo, row_map)", name ? name : "(null)");
   std::call_once(g_opt_once, opt_init);
   g_opt[i] = value;
   return SY11_OK;

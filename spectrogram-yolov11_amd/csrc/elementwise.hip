@@ -5,6 +5,7 @@
 // channel vector (VEC = 16 bytes of channels when alignment allows, else 1 element) and walks rows, so the
 // per-channel parameters are loaded once and every global access of a wave is a run of full 16-byte lanes.
 #include "common.h"
+#include "tune.h"
 
 template <typename T, int VEC> struct Vec {
   T v[VEC];
@@ -55,6 +56,43 @@ static bool vec_ok(int esz, int C, std::initializer_list<int> lds, std::initiali
   return true;
 }
 
+// Which rows a (block, trip, unrolled load) touches.  row = blockIdx.x*bs + trip*ts + u*us + rsub, for rows below `mend`:
+//   chunked (row_map 1, default): every block owns ONE contiguous run of `chunk` rows = 1-2 trips of U row groups and retires, so
+//     the chip sweeps the tensor front to back like a flat 1-D elementwise kernel.  Measured r02 on 210 MB f16 tensors
+//     (tools/bn_sweep.py): BN+SiLU apply 88.7 -> 75 us (5.6 TB/s), backward apply 130 -> 115 (5.4), reduce 101 -> 92;
+//     one trip pays the per-channel parameter loads too often for C >= 128 (122 us), four or more serialise on memory latency
+//     (84 / 92 us), two is the optimum;
+//   strided (row_map 0, the r01 mapping): a 2048-block grid walks the tensor with a grid-sized stride, U loads a whole grid apart.
+struct RowWalk {
+  long bs, ts, us, chunk;     // chunk = 0: strided
+  int grid;
+};
+static RowWalk row_walk(long M, int rows_pb, int U, int trips, long max_blocks) {
+  RowWalk w;
+  if (sy11_opt(OPT_ROW_MAP) == 0) {
+    long g = (M + rows_pb * (long)U - 1) / (rows_pb * (long)U);
+    const long cap = max_blocks < 2048 ? max_blocks : 2048;
+    g = g < 1 ? 1 : (g > cap ? cap : g);
+    w.grid = (int)g; w.bs = rows_pb; w.us = g * rows_pb; w.ts = w.us * U; w.chunk = 0;
+    return w;
+  }
+  const long unit = (long)rows_pb * U;
+  const long units = (M + unit - 1) / unit;
+  long t = trips < 1 ? 1 : trips;
+  long blocks = (units + t - 1) / t;
+  if (blocks > max_blocks) t = (units + max_blocks - 1) / max_blocks;
+  else if (blocks > 2048 && blocks < 6144) t = (units + 2047) / 2048;     // a partial second residency round costs more than longer blocks
+  const long chunk = unit * t;
+  w.chunk = chunk; w.bs = chunk; w.ts = unit; w.us = rows_pb;
+  w.grid = (int)((M + chunk - 1) / chunk);
+  return w;
+}
+__device__ __forceinline__ long walk_end(const RowWalk& w, long M) {
+  if (w.chunk == 0) return M;
+  const long e = ((long)blockIdx.x + 1) * w.chunk;
+  return e < M ? e : M;
+}
+
 // ------------------------------------------------------------------------------------------------ BN finalize
 __global__ __launch_bounds__(256) void bn_finalize_kernel(int C, int slots, double count, const float* __restrict__ ssum,
                                                           const float* __restrict__ ssq, const float* __restrict__ gamma,
@@ -102,28 +140,69 @@ extern "C" int sy11_bn_finalize(int32_t C, int32_t stat_slots, double count, con
 }
 
 // ------------------------------------------------------------------------------------------------ BN apply (+SiLU, +res)
+// Per-channel coefficients of the three BN passes go through LDS: thread e of a block prepares channel (cbase + e) ONCE, then every
+// thread reads its VEC channels back as 16-byte LDS vectors.  Loading them per thread from global memory is K x VEC scalars per thread
+// — for C >= 128 as many L1 requests as the block's data when a block makes one or two trips (r02: 80x80x256 apply 78 -> 122 us).
+// The first trip's data loads are issued BEFORE the barrier that publishes the coefficients, so their latencies overlap.
+extern __shared__ __attribute__((aligned(16))) float s_coef[];
+
+template <int VEC>
+__device__ __forceinline__ void coef_get(const float* arr, int cl0, float (&out)[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) out[i] = arr[cl0 + i];
+}
+struct RowLane {        // a thread's place in the row walk
+  int cl, cv, rsub, c, nch, cbase, cwv;
+  bool active;
+};
+template <int VEC>
+__device__ __forceinline__ RowLane row_lane(int cpv, int rows_pb) {
+  RowLane l;
+  const int cw = cpv < 256 ? cpv : 256;
+  l.cl = threadIdx.x % cw;
+  l.cv = blockIdx.y * 256 + l.cl;
+  l.rsub = threadIdx.x / cw;
+  l.c = l.cv * VEC;
+  l.nch = min(cw, cpv - (int)blockIdx.y * 256) * VEC;
+  l.cbase = blockIdx.y * 256 * VEC;
+  l.cwv = cw * VEC;
+  l.active = l.cv < cpv && l.rsub < rows_pb;
+  return l;
+}
+static inline size_t coef_bytes(const RowGeom& g, int vec, int k) { return (size_t)k * (g.cpv < 256 ? g.cpv : 256) * vec * sizeof(float); }
+
+template <typename T, int VEC, int U, bool RES>
+__device__ __forceinline__ void fwd_load(const T* y, int y_ld, const T* res, int res_ld, int c, long m, long us, long mend, float (&v)[U][VEC], float (&r)[U][VEC]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long mm = m + u * us < mend ? m + u * us : mend - 1;     // clamped: loads stay in bounds, stores are predicated
+    vload<T, VEC>(y + mm * y_ld + c, v[u]);
+    if (RES) vload<T, VEC>(res + mm * res_ld + c, r[u]);
+  }
+}
+
 template <typename T, int VEC, bool SILU, bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(long M, int C, const T* __restrict__ y, int y_ld, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res, int res_ld,
-                                                         T* __restrict__ z, int z_ld, int cpv, int rows_pb) {
+                                                         T* __restrict__ z, int z_ld, int cpv, int rows_pb, const RowWalk w) {
   constexpr int U = 4;                                   // rows in flight per thread (memory-level parallelism)
-  const int cw = cpv < 256 ? cpv : 256;
-  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
-  const int rsub = threadIdx.x / cw;
-  if (cv >= cpv || rsub >= rows_pb) return;
-  const int c = cv * VEC;
+  const RowLane l = row_lane<VEC>(cpv, rows_pb);
+  float* s_sc = s_coef;
+  float* s_sh = s_coef + l.cwv;
+  for (int e = threadIdx.x; e < l.nch; e += 256) {
+    s_sc[e] = scale ? scale[l.cbase + e] : 1.f;
+    s_sh[e] = shift ? shift[l.cbase + e] : 0.f;
+  }
+  const long mend = walk_end(w, M);
+  long m = (long)blockIdx.x * w.bs + l.rsub;
+  float v[U][VEC], r[U][VEC];
+  if (l.active && m < mend) fwd_load<T, VEC, U, RES>(y, y_ld, res, res_ld, l.c, m, w.us, mend, v, r);
+  __syncthreads();
+  if (!l.active) return;
   float sc[VEC], sh[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) { sc[i] = scale ? scale[c + i] : 1.f; sh[i] = shift ? shift[c + i] : 0.f; }
-  const long step = (long)gridDim.x * rows_pb;
-  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += step * U) {
-    float v[U][VEC], r[U][VEC];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long mm = m + u * step < M ? m + u * step : M - 1;     // clamped: loads stay in bounds, stores are predicated
-      vload<T, VEC>(y + mm * y_ld + c, v[u]);
-      if (RES) vload<T, VEC>(res + mm * res_ld + c, r[u]);
-    }
+  coef_get<VEC>(s_sc, l.cl * VEC, sc);
+  coef_get<VEC>(s_sh, l.cl * VEC, sh);
+  while (m < mend) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -133,18 +212,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(long M, int C, const T*
         if (RES) t += r[u][i];
         v[u][i] = t;
       }
-      if (m + u * step < M) vstore<T, VEC>(z + (m + u * step) * z_ld + c, v[u]);
+      if (m + u * w.us < mend) vstore<T, VEC>(z + (m + u * w.us) * z_ld + l.c, v[u]);
     }
+    m += w.ts;
+    if (m < mend) fwd_load<T, VEC, U, RES>(y, y_ld, res, res_ld, l.c, m, w.us, mend, v, r);
   }
 }
 
-static inline int row_grid(long M, int rows_pb) {
-  long g = (M + rows_pb * 4L - 1) / (rows_pb * 4L);        // 4 rows per thread per trip
-  const long cap = 256L * 8;
-  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
-}
-
-#define SY11_BNF(VV, SS, RR) hipLaunchKernelGGL((bn_act_fwd_kernel<T, VV, SS, RR>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, scale, shift, (const T*)res, res_ld, (T*)z, z_ld, g.cpv, g.rows_pb)
+#define SY11_BNF(VV, SS, RR) hipLaunchKernelGGL((bn_act_fwd_kernel<T, VV, SS, RR>), grid, block, coef_bytes(g, VV, 2), st, (long)M, C, (const T*)y, y_ld, scale, shift, (const T*)res, res_ld, (T*)z, z_ld, g.cpv, g.rows_pb, w)
 extern "C" int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const float* scale,
                                const float* shift, int32_t silu, const void* res, int32_t res_ld, void* z, int32_t z_ld,
                                void* stream) {
@@ -153,7 +228,8 @@ extern "C" int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* 
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {y_ld, z_ld, res ? res_ld : 16}, {y, z, res});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
-  dim3 grid(row_grid(M, g.rows_pb), g.cblocks), block(256);
+  const RowWalk w = row_walk(M, g.rows_pb, 4, 1, 1L << 20);
+  dim3 grid(w.grid, g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
@@ -165,57 +241,71 @@ extern "C" int sy11_bn_act_fwd(int32_t dtype, int64_t M, int32_t C, const void* 
 }
 
 // ------------------------------------------------------------------------------------------------ BN backward
-// pass 1: per-channel sums of g = dz*act'(u), u = y*scale+shift, and of g*xhat, xhat = (y-mean)*rstd
+template <typename T, int VEC, int U>
+__device__ __forceinline__ void bwd_load(const T* y, int y_ld, const T* dz, int dz_ld, int c, long m, long us, long mend, float (&vy)[U][VEC], float (&vg)[U][VEC]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long mm = m + u * us < mend ? m + u * us : mend - 1;
+    vload<T, VEC>(y + mm * y_ld + c, vy[u]);
+    vload<T, VEC>(dz + mm * dz_ld + c, vg[u]);
+  }
+}
+
+// pass 1: per-channel sums of g = dz*act'(u), u = y*scale+shift, and of g*xhat, xhat = (y-mean)*rstd (rstd applied once per block)
 template <typename T, int VEC, bool SILU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const T* __restrict__ y, int y_ld, const T* __restrict__ dz, int dz_ld,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            float* sum_g, float* sum_gx, int cpv, int rows_pb, int slots) {
+                                                            float* sum_g, float* sum_gx, int cpv, int rows_pb, int slots, const RowWalk w) {
   constexpr int U = 4;
   __shared__ float red[2][256][VEC > 1 ? VEC : 1];
-  const int cw = cpv < 256 ? cpv : 256;
-  const int cl = threadIdx.x % cw;
-  const int cv = blockIdx.y * 256 + cl;
-  const int rsub = threadIdx.x / cw;
-  const bool active = cv < cpv && rsub < rows_pb;
-  const int c = cv * VEC;
+  const RowLane l = row_lane<VEC>(cpv, rows_pb);
+  float* s_sc = s_coef;
+  float* s_sh = s_coef + l.cwv;
+  float* s_mu = s_coef + 2 * l.cwv;
+  for (int e = threadIdx.x; e < l.nch; e += 256) {
+    s_sc[e] = scale[l.cbase + e];
+    s_sh[e] = shift[l.cbase + e];
+    s_mu[e] = mean[l.cbase + e];
+  }
+  const long mend = walk_end(w, M);
+  long m = (long)blockIdx.x * w.bs + l.rsub;
+  float vy[U][VEC], vg[U][VEC];
+  if (l.active && m < mend) bwd_load<T, VEC, U>(y, y_ld, dz, dz_ld, l.c, m, w.us, mend, vy, vg);
+  __syncthreads();
   float sg[VEC], sgx[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) sg[i] = sgx[i] = 0.f;
-  if (active) {
-    float mu[VEC], rs[VEC], sc[VEC], sh[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { mu[i] = mean[c + i]; rs[i] = rstd[c + i]; sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
-    const long step = (long)gridDim.x * rows_pb;
-    for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += step * U) {
-      float vy[U][VEC], vg[U][VEC];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const long mm = m + u * step < M ? m + u * step : M - 1;
-        vload<T, VEC>(y + mm * y_ld + c, vy[u]);
-        vload<T, VEC>(dz + mm * dz_ld + c, vg[u]);
-      }
+  if (l.active) {
+    float mu[VEC], sc[VEC], sh[VEC];
+    coef_get<VEC>(s_mu, l.cl * VEC, mu);
+    coef_get<VEC>(s_sc, l.cl * VEC, sc);
+    coef_get<VEC>(s_sh, l.cl * VEC, sh);
+    while (m < mend) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float live = (m + u * step < M) ? 1.f : 0.f;
+        const float live = (m + u * w.us < mend) ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           float g = vg[u][i] * live;
           if (SILU) g *= dsilu_f(vy[u][i] * sc[i] + sh[i]);
           sg[i] += g;
-          sgx[i] += g * (vy[u][i] - mu[i]) * rs[i];
+          sgx[i] += g * (vy[u][i] - mu[i]);
         }
       }
+      m += w.ts;
+      if (m < mend) bwd_load<T, VEC, U>(y, y_ld, dz, dz_ld, l.c, m, w.us, mend, vy, vg);
     }
   }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { red[0][threadIdx.x][i] = sg[i]; red[1][threadIdx.x][i] = sgx[i]; }
   __syncthreads();
   // tree reduction over the row groups (all threads take part; rows_pb need not be a power of two)
+  const int cw = l.cwv / VEC;
   int half = 1;
   while (half < rows_pb) half <<= 1;
   for (half >>= 1; half >= 1; half >>= 1) {
-    if (rsub < half && rsub + half < rows_pb) {
+    if (l.rsub < half && l.rsub + half < rows_pb) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         red[0][threadIdx.x][i] += red[0][threadIdx.x + half * cw][i];
@@ -224,20 +314,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const
     }
     __syncthreads();
   }
-  // dense atomics: lane t adds channel (blockIdx.y*256*VEC + t) -> one 256-byte request group per 64 lanes instead of
-  // VEC-strided scalars (same-line atomic REQUESTS, not bytes, are what the memory side serialises)
-  {
-    const int nch = min(cw, cpv - blockIdx.y * 256) * VEC;
-    for (int e = threadIdx.x; e < nch; e += 256) {
-      const int cl2 = e / VEC, i2 = e - cl2 * VEC;
-      const long ch = (long)(blockIdx.x % slots) * C + blockIdx.y * 256 * VEC + e;
-      atomicAdd(sum_g + ch, red[0][cl2][i2]);
-      atomicAdd(sum_gx + ch, red[1][cl2][i2]);
-    }
+  // dense atomics: lane t adds channel (cbase + t) -> one 256-byte request group per 64 lanes instead of VEC-strided scalars
+  // (same-line atomic REQUESTS, not bytes, are what the memory side serialises)
+  for (int e = threadIdx.x; e < l.nch; e += 256) {
+    const int cl2 = e / VEC, i2 = e - cl2 * VEC;
+    const long ch = (long)(blockIdx.x % slots) * C + l.cbase + e;
+    atomicAdd(sum_g + ch, red[0][cl2][i2]);
+    atomicAdd(sum_gx + ch, red[1][cl2][i2] * rstd[l.cbase + e]);
   }
 }
 
-#define SY11_BNR(VV, SS) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VV, SS>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, sum_g, sum_gx, g.cpv, g.rows_pb, slots)
+#define SY11_BNR(VV, SS) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VV, SS>), grid, block, coef_bytes(g, VV, 3), st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, sum_g, sum_gx, g.cpv, g.rows_pb, slots, w)
 extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                                       int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
                                       const float* shift, int32_t silu, float* sum_g, float* sum_gx, int32_t sum_slots,
@@ -247,12 +334,12 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {y_ld, dz_ld}, {y, dz});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
-  long nblk = (M + g.rows_pb * 4L - 1) / (g.rows_pb * 4L);     // small maps: one trip of 4 rows per thread (a second, dependent trip
-  if (nblk > 640) nblk = (M + g.rows_pb * 8L - 1) / (g.rows_pb * 8L);   // costs a memory round trip: 7.4 -> 5.7 us); larger ones: >= 8 rows
-  if (nblk > 2048) nblk = 2048;
-  if (nblk < 1) nblk = 1;
+  // small maps: one trip of 4 rows per thread (a second, dependent trip costs a memory round trip: 7.4 -> 5.7 us); larger ones >= 8 rows;
+  // at most 4096 blocks (each ends in a tree reduction and 2 x C atomics)
+  const long nb4 = (M + g.rows_pb * 4L - 1) / (g.rows_pb * 4L);
+  const RowWalk w = row_walk(M, g.rows_pb, 4, nb4 > 640 ? 2 : 1, 4096);
   const int slots = sum_slots > 1 ? sum_slots : 1;
-  dim3 grid((unsigned)nblk, g.cblocks), block(256);
+  dim3 grid(w.grid, g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
@@ -263,69 +350,69 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
   return SY11_OK;
 }
 
-// pass 2: dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); block (0,*) also accumulates dgamma/dbeta
+// pass 2: dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M) = k0*g - k1 - (y - mean)*k2; block (0,*) also accumulates dgamma/dbeta
 template <typename T, int VEC, bool SILU>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const T* __restrict__ y, int y_ld, const T* __restrict__ dz, int dz_ld,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                            const float* __restrict__ sum_gx, T* __restrict__ dy, int dy_ld, float* dgamma,
-                                                           float* dbeta, int cpv, int rows_pb, int slots) {
+                                                           float* dbeta, int cpv, int rows_pb, int slots, const RowWalk w) {
   constexpr int U = 4;
-  __shared__ float s_tot[2][256 * VEC];
-  const int cw = cpv < 256 ? cpv : 256;
-  const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
-  const int rsub = threadIdx.x / cw;
-  // fold the partial-sum slots ONCE per workgroup (channel e of this block's range per thread), share through LDS
+  const RowLane l = row_lane<VEC>(cpv, rows_pb);
+  float* s_sc = s_coef;
+  float* s_sh = s_coef + l.cwv;
+  float* s_mu = s_coef + 2 * l.cwv;
+  float* s_k0 = s_coef + 3 * l.cwv;
+  float* s_k1 = s_coef + 4 * l.cwv;
+  float* s_k2 = s_coef + 5 * l.cwv;
+  const long mend = walk_end(w, M);
+  long m = (long)blockIdx.x * w.bs + l.rsub;
+  float vy[U][VEC], vg[U][VEC];
+  if (l.active && m < mend) bwd_load<T, VEC, U>(y, y_ld, dz, dz_ld, l.c, m, w.us, mend, vy, vg);
   {
-    const int nch = min(cw, cpv - (int)blockIdx.y * 256) * VEC;
-    const int cbase = blockIdx.y * 256 * VEC;
-    for (int e = threadIdx.x; e < nch; e += 256) {
+    // channel e of this block's range per thread: fold the partial-sum slots, derive the three coefficients
+    const float invM = 1.0f / (float)M;
+    for (int e = threadIdx.x; e < l.nch; e += 256) {
+      const int ch = l.cbase + e;
       float tg = 0.f, tgx = 0.f;
-      for (int k = 0; k < slots; ++k) { tg += sum_g[(long)k * C + cbase + e]; tgx += sum_gx[(long)k * C + cbase + e]; }
-      s_tot[0][e] = tg;
-      s_tot[1][e] = tgx;
-      if (blockIdx.x == 0 && dgamma) { atomicAdd(dgamma + cbase + e, tgx); atomicAdd(dbeta + cbase + e, tg); }
+      for (int k = 0; k < slots; ++k) { tg += sum_g[(long)k * C + ch]; tgx += sum_gx[(long)k * C + ch]; }
+      if (blockIdx.x == 0 && dgamma) { atomicAdd(dgamma + ch, tgx); atomicAdd(dbeta + ch, tg); }
+      const float rs = rstd[ch], gr = gamma[ch] * rs;
+      s_sc[e] = scale[ch];
+      s_sh[e] = shift[ch];
+      s_mu[e] = mean[ch];
+      s_k0[e] = gr;
+      s_k1[e] = gr * tg * invM;
+      s_k2[e] = gr * tgx * invM * rs;
     }
   }
   __syncthreads();
-  if (cv >= cpv || rsub >= rows_pb) return;
-  const int c = cv * VEC;
-  const int cl0 = (threadIdx.x % cw) * VEC;
-  const float invM = 1.0f / (float)M;
-  float mu[VEC], rs[VEC], sc[VEC], sh[VEC], k0[VEC], k1[VEC], k2[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    mu[i] = mean[c + i]; rs[i] = rstd[c + i]; sc[i] = scale[c + i]; sh[i] = shift[c + i];
-    const float gr = gamma[c + i] * rs[i];
-    k0[i] = gr;
-    k1[i] = gr * s_tot[0][cl0 + i] * invM;
-    k2[i] = gr * s_tot[1][cl0 + i] * invM;
-  }
-  const long step = (long)gridDim.x * rows_pb;
-  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += step * U) {
-    float vy[U][VEC], vg[U][VEC];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long mm = m + u * step < M ? m + u * step : M - 1;
-      vload<T, VEC>(y + mm * y_ld + c, vy[u]);
-      vload<T, VEC>(dz + mm * dz_ld + c, vg[u]);
-    }
+  if (!l.active) return;
+  float mu[VEC], sc[VEC], sh[VEC], k0[VEC], k1[VEC], k2[VEC];
+  coef_get<VEC>(s_mu, l.cl * VEC, mu);
+  coef_get<VEC>(s_sc, l.cl * VEC, sc);
+  coef_get<VEC>(s_sh, l.cl * VEC, sh);
+  coef_get<VEC>(s_k0, l.cl * VEC, k0);
+  coef_get<VEC>(s_k1, l.cl * VEC, k1);
+  coef_get<VEC>(s_k2, l.cl * VEC, k2);
+  while (m < mend) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         float g = vg[u][i];
         if (SILU) g *= dsilu_f(vy[u][i] * sc[i] + sh[i]);
-        const float xhat = (vy[u][i] - mu[i]) * rs[i];
-        vg[u][i] = k0[i] * g - k1[i] - xhat * k2[i];
+        vg[u][i] = k0[i] * g - k1[i] - (vy[u][i] - mu[i]) * k2[i];
       }
-      if (m + u * step < M) vstore<T, VEC>(dy + (m + u * step) * dy_ld + c, vg[u]);
+      if (m + u * w.us < mend) vstore<T, VEC>(dy + (m + u * w.us) * dy_ld + l.c, vg[u]);
     }
+    m += w.ts;
+    if (m < mend) bwd_load<T, VEC, U>(y, y_ld, dz, dz_ld, l.c, m, w.us, mend, vy, vg);
   }
 }
 
-#define SY11_BNA(VV, SS) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VV, SS>), grid, block, 0, st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb, sum_slots > 1 ? sum_slots : 1)
+#define SY11_BNA(VV, SS) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VV, SS>), grid, block, coef_bytes(g, VV, 6), st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb, sum_slots > 1 ? sum_slots : 1, w)
 extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                                      int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
                                      const float* shift, const float* gamma, int32_t silu, const float* sum_g,
@@ -337,7 +424,8 @@ extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const 
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {y_ld, dz_ld, dy_ld}, {y, dz, dy});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
-  dim3 grid(row_grid(M, g.rows_pb), g.cblocks), block(256);
+  const RowWalk w = row_walk(M, g.rows_pb, 4, 2, 1L << 20);          // the slot fold of the prologue is paid per block: two trips
+  dim3 grid(w.grid, g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
@@ -346,6 +434,12 @@ extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const 
   });
   SY11_LAUNCH_CHECK("bn_act_bwd_apply");
   return SY11_OK;
+}
+
+static inline int row_grid(long M, int rows_pb) {
+  long g = (M + rows_pb * 4L - 1) / (rows_pb * 4L);        // 4 rows per thread per trip
+  const long cap = 256L * 8;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
 // ------------------------------------------------------------------------------------------------ strided copy / accumulate

@@ -397,33 +397,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
     __syncthreads();
     const int cpr = rowb / 16;                       // 16-byte chunks per tile row
     const int epc_o = 16 / osz;
-    for (int idx = tid; idx < BM * cpr; idx += 256) {
-      const int rl = idx / cpr, ch = idx - rl * cpr;
-      const int m = bm0 + rl, n = bn0 + ch * epc_o;
-      if (m >= a.M || n >= a.N || a.debug == 5) continue;   // N % epc_o == 0 is guaranteed by the host; debug 5 = tuner dry run
-      long obase;
-      if (a.dense_out) {
-        obase = (long)m * a.y_ld;
-      } else {
-        const int b = m / ohw, r = m - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
-        obase = ((long)(b * a.OHF + oy * a.oy_mul + a.oy_add) * a.OWF + ox * a.ox_mul + a.ox_add) * a.y_ld;
-      }
-      uint4 v = *(const uint4*)(smem + rl * rowb + ch * 16);
-      unsigned char* gp = (unsigned char*)a.y + (obase + n) * osz;
-      if (accum) {
-        const uint4 o = *(const uint4*)gp;
-        if (out32) {
-          f32x4 x = __builtin_bit_cast(f32x4, v), y = __builtin_bit_cast(f32x4, o);
-          v = __builtin_bit_cast(uint4, x + y);
-        } else {
-          typedef T vt8 __attribute__((ext_vector_type(16 / sizeof(T))));
-          vt8 x = __builtin_bit_cast(vt8, v), y = __builtin_bit_cast(vt8, o);
+    // four 16-byte chunks per thread per trip; an accumulating epilogue issues its four reads of y before the first add, so a
+    // thread waits for ONE memory round trip per trip instead of one per chunk
+    constexpr int U = 4;
+    for (int base = tid; base < BM * cpr; base += 256 * U) {
+      unsigned char* gp[U];
+      uint4 o[U];
+      int lofs[U];
 #pragma unroll
-          for (int q = 0; q < (int)(16 / sizeof(T)); ++q) x[q] = ElemTraits<T>::from_f(ElemTraits<T>::to_f(x[q]) + ElemTraits<T>::to_f(y[q]));
-          v = __builtin_bit_cast(uint4, x);
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * 256;
+        const int rl = idx / cpr, ch = idx - rl * cpr;
+        const int m = bm0 + rl, n = bn0 + ch * epc_o;
+        // N % epc_o == 0 is guaranteed by the host; debug 5 = tuner dry run
+        const bool ok = idx < BM * cpr && m < a.M && n < a.N && a.debug != 5;
+        long obase;
+        if (a.dense_out) {
+          obase = (long)m * a.y_ld;
+        } else {
+          const int b = m / ohw, r = m - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
+          obase = ((long)(b * a.OHF + oy * a.oy_mul + a.oy_add) * a.OWF + ox * a.ox_mul + a.ox_add) * a.y_ld;
         }
+        gp[u] = ok ? (unsigned char*)a.y + (obase + n) * osz : nullptr;
+        lofs[u] = rl * rowb + ch * 16;
+        if (accum && ok) o[u] = *(const uint4*)gp[u];
       }
-      *(uint4*)gp = v;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!gp[u]) continue;
+        uint4 v = *(const uint4*)(smem + lofs[u]);
+        if (accum) {
+          if (out32) {
+            f32x4 x = __builtin_bit_cast(f32x4, v), y = __builtin_bit_cast(f32x4, o[u]);
+            v = __builtin_bit_cast(uint4, x + y);
+          } else {
+            typedef T vt8 __attribute__((ext_vector_type(16 / sizeof(T))));
+            vt8 x = __builtin_bit_cast(vt8, v), y = __builtin_bit_cast(vt8, o[u]);
+#pragma unroll
+            for (int q = 0; q < (int)(16 / sizeof(T)); ++q) x[q] = ElemTraits<T>::from_f(ElemTraits<T>::to_f(x[q]) + ElemTraits<T>::to_f(y[q]));
+            v = __builtin_bit_cast(uint4, x);
+          }
+        }
+        *(uint4*)gp[u] = v;
+      }
     }
   } else {
 #pragma unroll
@@ -809,10 +825,11 @@ extern "C" int sy11_conv2d_dgrad(const sy11_conv_desc* d, const void* dy, int32_
   SY11_REQUIRE(!(d->flags & (SY11_EPI_SILU | SY11_EPI_OUT_F32)), "conv2d_dgrad: only SY11_EPI_ACCUM is meaningful");
   // 3x3 / stride 2 / pad 1 in f16: all four parity classes in ONE pass over dy (conv3x3.hip halo_dgrad_s2_kernel), unless switched off
   if (d->dtype == SY11_F16 && d->KH == 3 && d->KW == 3 && d->SH == 2 && d->SW == 2 && d->PH == 1 && d->PW == 1 && d->DH == 1 && d->DW == 1 &&
-      sy11_opt(OPT_IGEMM_CFG) < 0 && (sy11_opt(OPT_DGRAD_S2_HALO) == 2 || (sy11_opt(OPT_DGRAD_S2_HALO) == 1 && d->C <= 64))) {
-    // default (1): only where dx has <= 64 channels = ONE channel tile per dy patch — 413 -> 170 us on 320x320x32 <- 160x160x64; with
-    // 128 / 256 dx channels the 64-wide tiles re-read the patch 2-4x and one workgroup per CU loses to the four igemm launches
-    // (284 -> 315, 236 -> 299 us).  2 = always (tests).
+      sy11_opt(OPT_IGEMM_CFG) < 0 && (sy11_opt(OPT_DGRAD_S2_HALO) == 2 || (sy11_opt(OPT_DGRAD_S2_HALO) == 1 && (d->C <= 64 || (!(d->flags & SY11_EPI_ACCUM) && d->N <= d->C && d->C <= 256))))) {
+    // default (1): where dx has <= 64 channels (320x320x32 <- 160x160x64: 402 -> 182 us, accumulating 520 -> 251), or a plain store of
+    // <= 256 channels with dy no wider than dx (160x160x128 <- 80x80x128: 274 -> 259 us).  Elsewhere the four tuned igemm launches
+    // win: accumulating into 128+ channels (448 vs 493, 284 vs 307, 107 vs 119 us — one workgroup per CU cannot hide the reads of dx),
+    // four channel tiles per dy patch (40x40x512 <- 20x20x512: 176 vs 213 us), dy twice as wide as dx.  2 = always (tests).
     IgemmArgs a{};
     a.x = dy; a.w = wt; a.y = dx;
     a.C = d->N; a.wK = 9 * d->N; a.N = d->C; a.K = 9 * d->N; a.T = 9;

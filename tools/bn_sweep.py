@@ -1,16 +1,53 @@
 """Time the BatchNorm+SiLU passes (fwd apply, bwd reduce, bwd apply) on every BN'd conv output shape of yolo11s
-(640x640, batch 64, f16) and print achieved HBM bandwidth.   python tools/bn_sweep.py [-v]"""
+(640x640, batch 64, f16) and print achieved HBM bandwidth.   python tools/bn_sweep.py [-v] [--row-map 0|1] [--eager]
+Launches are timed inside a replayed hipGraph of 10 calls (what the trainer runs; a small kernel's eager time is the host's call
+rate, not the kernel); --eager times plain calls.  --row-map: the row walk of the kernels (elementwise.hip RowWalk), default both."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "spectrogram-yolov11_amd"))
 sys.path.insert(0, str(ROOT / "tools"))
 import torch
-from sy11 import ops
+from sy11 import _lib, ops
 from conv_sweep import LAYERS
 
 
+def timed(fn, reps, eager):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if eager:
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+    else:
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.cuda.graph(g, stream=side):
+            for _ in range(reps):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def main():
+    maps = [int(v) for v in sys.argv[sys.argv.index("--row-map") + 1].split(",")] if "--row-map" in sys.argv else [0, 1]
+    for rm in maps:
+        _lib.set_option("row_map", rm)
+        print(f"row_map = {rm} ({'chunked' if rm else 'strided (r01)'})")
+        sweep("--eager" in sys.argv)
+
+
+def sweep(eager):
     verbose = "-v" in sys.argv
     B, dt, reps = 64, torch.float16, 10
     tot = {"fwd": 0.0, "reduce": 0.0, "apply": 0.0}
@@ -26,23 +63,14 @@ def main():
         dy = torch.empty_like(y)
         f = lambda *sh: torch.rand(*sh, device="cuda") + 0.5
         mean, rstd, scale, shift, gamma = f(N), f(N), f(N), f(N), f(N)
-        sg, sgx = torch.zeros(32, N, device="cuda"), torch.zeros(32, N, device="cuda")
+        sg, sgx = torch.zeros(8, N, device="cuda"), torch.zeros(8, N, device="cuda")      # 8 slots, as nn/modules/conv.py
         dgam, dbet = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
         fns = {"fwd": (lambda: ops.bn_act_fwd(y, scale, shift, z, True), 2),
                "reduce": (lambda: ops.bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, True, sg, sgx), 2),
                "apply": (lambda: ops.bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, True, sg, sgx, dy, dgam, dbet), 3)}
         row = f"{OH:3d}x{OW:<3d}x{N:<4d} x{cnt:<2d}"
         for name, (fn, passes) in fns.items():
-            for _ in range(2):
-                fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
+            ms = timed(fn, reps, eager)
             nb = passes * y.numel() * 2
             tot[name] += ms * cnt
             byt[name] += nb * cnt
