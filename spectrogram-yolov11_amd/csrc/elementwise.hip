@@ -445,23 +445,30 @@ static inline int row_grid(long M, int rows_pb) {
 // ------------------------------------------------------------------------------------------------ strided copy / accumulate
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void copy2d_kernel(long M, int C, const T* __restrict__ src, int src_ld, T* __restrict__ dst, int dst_ld,
-                                                     int accumulate, int cpv, int rows_pb) {
+                                                     int accumulate, int cpv, int rows_pb, const RowWalk w) {
+  constexpr int U = 4;
   const int cw = cpv < 256 ? cpv : 256;
   const int cv = blockIdx.y * 256 + (threadIdx.x % cw);
   const int rsub = threadIdx.x / cw;
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
-#pragma unroll 4
-  for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
-    float v[VEC];
-    vload<T, VEC>(src + m * src_ld + c, v);
-    if (accumulate) {
-      float o[VEC];
-      vload<T, VEC>(dst + m * dst_ld + c, o);
+  const long mend = walk_end(w, M);
+  for (long m = (long)blockIdx.x * w.bs + rsub; m < mend; m += w.ts) {
+    float v[U][VEC], o[U][VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) v[i] += o[i];
+    for (int u = 0; u < U; ++u) {
+      const long mm = m + u * w.us < mend ? m + u * w.us : mend - 1;
+      vload<T, VEC>(src + mm * src_ld + c, v[u]);
+      if (accumulate) vload<T, VEC>(dst + mm * dst_ld + c, o[u]);
     }
-    vstore<T, VEC>(dst + m * dst_ld + c, v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (accumulate) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[u][i] += o[u][i];
+      }
+      if (m + u * w.us < mend) vstore<T, VEC>(dst + (m + u * w.us) * dst_ld + c, v[u]);
+    }
   }
 }
 
@@ -472,12 +479,13 @@ extern "C" int sy11_copy2d(int32_t dtype, int64_t M, int32_t C, const void* src,
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {src_ld, dst_ld}, {src, dst});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
-  dim3 grid(row_grid(M, g.rows_pb), g.cblocks), block(256);
+  const RowWalk w = row_walk(M, g.rows_pb, 4, 1, 1L << 20);
+  dim3 grid(w.grid, g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
-    if (v) hipLaunchKernelGGL((copy2d_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)src, src_ld, (T*)dst, dst_ld, accumulate, g.cpv, g.rows_pb);
-    else hipLaunchKernelGGL((copy2d_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)src, src_ld, (T*)dst, dst_ld, accumulate, g.cpv, g.rows_pb);
+    if (v) hipLaunchKernelGGL((copy2d_kernel<T, VE>), grid, block, 0, st, (long)M, C, (const T*)src, src_ld, (T*)dst, dst_ld, accumulate, g.cpv, g.rows_pb, w);
+    else hipLaunchKernelGGL((copy2d_kernel<T, 1>), grid, block, 0, st, (long)M, C, (const T*)src, src_ld, (T*)dst, dst_ld, accumulate, g.cpv, g.rows_pb, w);
   });
   SY11_LAUNCH_CHECK("copy2d");
   return SY11_OK;
@@ -495,9 +503,10 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(int B, int H, int W
   const long M = (long)B * H * W;
 #pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
-    const int w = (int)(m % W);
-    const long t = m / W;
-    const int h = (int)(t % H), b = (int)(t / H);
+    const unsigned mi = (unsigned)m;                     // B*H*W < 2^31 (checked by the host): 32-bit division, not the emulated 64-bit one
+    const unsigned t = mi / (unsigned)W;
+    const int w = (int)(mi - t * (unsigned)W);
+    const int b = (int)(t / (unsigned)H), h = (int)(t - (unsigned)b * (unsigned)H);
     float v[VEC];
     vload<T, VEC>(x + m * x_ld + c, v);
     const long o = ((long)(b * 2 * H + 2 * h) * (2 * W) + 2 * w);
@@ -518,9 +527,10 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(int B, int H, int W
   const long M = (long)B * H * W;
 #pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
-    const int w = (int)(m % W);
-    const long t = m / W;
-    const int h = (int)(t % H), b = (int)(t / H);
+    const unsigned mi = (unsigned)m;                     // B*H*W < 2^31 (checked by the host): 32-bit division, not the emulated 64-bit one
+    const unsigned t = mi / (unsigned)W;
+    const int w = (int)(mi - t * (unsigned)W);
+    const int b = (int)(t / (unsigned)H), h = (int)(t - (unsigned)b * (unsigned)H);
     const long o = ((long)(b * 2 * H + 2 * h) * (2 * W) + 2 * w);
     float a[VEC], q[VEC];
     vload<T, VEC>(dy + o * dy_ld + c, a);
@@ -545,6 +555,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(int B, int H, int W
 extern "C" int sy11_upsample2x_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, int32_t x_ld,
                                    void* y, int32_t y_ld, void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && x && y && x_ld >= C && y_ld >= C, "upsample2x_fwd: bad argument");
+  SY11_REQUIRE((long)B * H * W < (1L << 31), "upsample2x_fwd: too many pixels");
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {x_ld, y_ld}, {x, y});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
@@ -561,6 +572,7 @@ extern "C" int sy11_upsample2x_fwd(int32_t dtype, int32_t B, int32_t H, int32_t 
 extern "C" int sy11_upsample2x_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
                                    void* dx, int32_t dx_ld, int32_t accumulate, void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && dy && dx && dy_ld >= C && dx_ld >= C, "upsample2x_bwd: bad argument");
+  SY11_REQUIRE((long)B * H * W < (1L << 31), "upsample2x_bwd: too many pixels");
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {dy_ld, dx_ld}, {dy, dx});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
@@ -576,6 +588,9 @@ extern "C" int sy11_upsample2x_bwd(int32_t dtype, int32_t B, int32_t H, int32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ 5x5 stride-1 max pool
+// Both kernels are branch-free over the 25 window positions: a position outside the map loads a clamped (always legal) pixel and is
+// neutralised arithmetically, so the 5 loads of a window row go out back to back instead of one branch-and-wait per position.
+// ATen's rule: the first maximum in row-major window order wins, NaN propagates.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(int B, int H, int W, int C, const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld,
                                                            uint8_t* __restrict__ idx, int cpv, int rows_pb) {
@@ -585,34 +600,90 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(int B, int H, int W, 
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
   const long M = (long)B * H * W;
-#pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
-    const int w = (int)(m % W);
-    const long t = m / W;
-    const int h = (int)(t % H), b = (int)(t / H);
+    const unsigned mi = (unsigned)m;                     // B*H*W < 2^31 (checked by the host): 32-bit division, not the emulated 64-bit one
+    const unsigned t = mi / (unsigned)W;
+    const int w = (int)(mi - t * (unsigned)W);
+    const int h = (int)(t % (unsigned)H);
+    // legal window rows / columns as bit masks, tested where a position is USED: 25 long-lived lane masks spill the scalar registers
+    unsigned rmask = 0, cmask = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      rmask |= ((unsigned)(h + k - 2) < (unsigned)H ? 1u : 0u) << k;
+      cmask |= ((unsigned)(w + k - 2) < (unsigned)W ? 1u : 0u) << k;
+    }
+    const T* xc = x + (m - (long)h * W - w) * x_ld + c;        // pixel (0, 0) of this image
     float best[VEC];
     int bi[VEC];
+    if constexpr (sizeof(T) == 2) {
+      // 16-bit inputs: value and window position share ONE sortable integer.  A 16-bit float widened to f32 has >= 13 zero low bits;
+      // ord = bits ^ ((bits >> 31) & 0x7fffffe0) orders like the float (sign-magnitude -> two's complement) and keeps the low 5 bits
+      // free for 25 - pos (earlier position = larger key = wins a tie, ATen's rule).  An illegal position loads a clamped duplicate of
+      // a legal pixel with low bits 0, so it loses the tie against its twin: no per-element masks at all (the compare-and-select form
+      // keeps 200 lane masks alive and spills the scalar registers).  +0 outranks -0 (ATen: whichever comes first).
+      int key[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; bi[i] = 12; }
-    bool first = true;
-    for (int wy = 0; wy < 5; ++wy) {
-      const int iy = h + wy - 2;
-      if ((unsigned)iy >= (unsigned)H) continue;
-      for (int wx = 0; wx < 5; ++wx) {
-        const int ix = w + wx - 2;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        float v[VEC];
-        vload<T, VEC>(x + ((long)(b * H + iy) * W + ix) * x_ld + c, v);
+      for (int i = 0; i < VEC; ++i) key[i] = (int)0x80000000;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i)
-          if (first || v[i] > best[i]) { best[i] = v[i]; bi[i] = wy * 5 + wx; }   // strict >: first maximum wins
-        first = false;
+      for (int wy = 0; wy < 5; ++wy) {
+        const int iy = min(max(h + wy - 2, 0), H - 1);         // clamped: always a legal address
+        float v[5][VEC];
+#pragma unroll
+        for (int wx = 0; wx < 5; ++wx) {
+          const int ix = min(max(w + wx - 2, 0), W - 1);
+          vload<T, VEC>(xc + ((long)iy * W + ix) * x_ld, v[wx]);
+        }
+#pragma unroll
+        for (int wx = 0; wx < 5; ++wx) {
+          const int low = (int)((rmask >> wy) & (cmask >> wx) & 1u) * (25 - (wy * 5 + wx));
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const int bits = __builtin_bit_cast(int, v[wx][i]);
+            const int k = (bits ^ ((bits >> 31) & 0x7fffffe0)) + low;
+            key[i] = k > key[i] ? k : key[i];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        bi[i] = 25 - (key[i] & 31);
+        const int o = key[i] & ~31;
+        best[i] = __builtin_bit_cast(float, o ^ ((o >> 31) & 0x7fffffe0));
+      }
+    } else {
+      const int y0 = max(0, 2 - h), x0 = max(0, 2 - w);        // first legal position in row-major order: taken unconditionally
+      vload<T, VEC>(xc + ((long)(h + y0 - 2) * W + (w + x0 - 2)) * x_ld, best);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) bi[i] = y0 * 5 + x0;
+#pragma unroll
+      for (int wy = 0; wy < 5; ++wy) {
+        const int iy = min(max(h + wy - 2, 0), H - 1);
+        float v[5][VEC];
+#pragma unroll
+        for (int wx = 0; wx < 5; ++wx) {
+          const int ix = min(max(w + wx - 2, 0), W - 1);
+          vload<T, VEC>(xc + ((long)iy * W + ix) * x_ld, v[wx]);
+        }
+#pragma unroll
+        for (int wx = 0; wx < 5; ++wx) {
+          const bool ok = ((rmask >> wy) & (cmask >> wx) & 1u) != 0;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i)
+            if (ok && v[wx][i] > best[i]) { best[i] = v[wx][i]; bi[i] = wy * 5 + wx; }   // strict >: first maximum wins
+        }
       }
     }
     vstore<T, VEC>(y + m * y_ld + c, best);
     if (idx) {
+      if constexpr (VEC == 8) {
+        uint2 pk;
+        pk.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+        pk.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+        *(uint2*)(idx + m * C + c) = pk;                // C % 8 == 0 and c % 8 == 0 on the vector path
+      } else {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) idx[m * C + c + i] = (uint8_t)bi[i];
+        for (int i = 0; i < VEC; ++i) idx[m * C + c + i] = (uint8_t)bi[i];
+      }
     }
   }
 }
@@ -626,35 +697,43 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(int B, int H, int W, 
   if (cv >= cpv || rsub >= rows_pb) return;
   const int c = cv * VEC;
   const long M = (long)B * H * W;
-#pragma unroll 4
   for (long m = (long)blockIdx.x * rows_pb + rsub; m < M; m += (long)gridDim.x * rows_pb) {
-    const int w = (int)(m % W);
-    const long t = m / W;
-    const int h = (int)(t % H), b = (int)(t / H);
+    const unsigned mi = (unsigned)m;                     // B*H*W < 2^31 (checked by the host): 32-bit division, not the emulated 64-bit one
+    const unsigned t = mi / (unsigned)W;
+    const int w = (int)(mi - t * (unsigned)W);
+    const int h = (int)(t % (unsigned)H);
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    if (accumulate) vload<T, VEC>(dx + m * dx_ld + c, acc);
     // every window q = p + (oy, ox) that contains p; p sits at window position (2-oy, 2-ox) of q
+#pragma unroll
     for (int oy = -2; oy <= 2; ++oy) {
-      const int qy = h + oy;
-      if ((unsigned)qy >= (unsigned)H) continue;
+      const bool yok = (unsigned)(h + oy) < (unsigned)H;
+      float g[5][VEC];
+      uint8_t pi[5][VEC];
+#pragma unroll
       for (int ox = -2; ox <= 2; ++ox) {
-        const int qx = w + ox;
-        if ((unsigned)qx >= (unsigned)W) continue;
-        const long q = (long)(b * H + qy) * W + qx;
+        const bool ok = yok && (unsigned)(w + ox) < (unsigned)W;
+        const long q = m + (ok ? (long)oy * W + ox : 0);
+        vload<T, VEC>(dy + q * dy_ld + c, g[ox + 2]);
+        if constexpr (VEC == 8) {
+          const uint2 pk = *(const uint2*)(idx + q * C + c);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { pi[ox + 2][i] = (uint8_t)(pk.x >> (8 * i)); pi[ox + 2][4 + i] = (uint8_t)(pk.y >> (8 * i)); }
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) pi[ox + 2][i] = idx[q * C + c + i];
+        }
+      }
+#pragma unroll
+      for (int ox = -2; ox <= 2; ++ox) {
+        const bool ok = yok && (unsigned)(w + ox) < (unsigned)W;
         const int pos = (2 - oy) * 5 + (2 - ox);
-        float g[VEC];
-        vload<T, VEC>(dy + q * dy_ld + c, g);
 #pragma unroll
         for (int i = 0; i < VEC; ++i)
-          if (idx[q * C + c + i] == pos) acc[i] += g[i];
+          if (ok && pi[ox + 2][i] == pos) acc[i] += g[ox + 2][i];
       }
-    }
-    if (accumulate) {
-      float o[VEC];
-      vload<T, VEC>(dx + m * dx_ld + c, o);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] += o[i];
     }
     vstore<T, VEC>(dx + m * dx_ld + c, acc);
   }
@@ -663,6 +742,7 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(int B, int H, int W, 
 extern "C" int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, int32_t x_ld,
                                  void* y, int32_t y_ld, uint8_t* idx, void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && x && y && x_ld >= C && y_ld >= C, "maxpool5_fwd: bad argument");
+  SY11_REQUIRE((long)B * H * W < (1L << 31), "maxpool5_fwd: too many pixels");
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {x_ld, y_ld}, {x, y});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
@@ -679,6 +759,7 @@ extern "C" int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W,
 extern "C" int sy11_maxpool5_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
                                  const uint8_t* idx, void* dx, int32_t dx_ld, int32_t accumulate, void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && dy && dx && idx && dy_ld >= C && dx_ld >= C, "maxpool5_bwd: bad argument");
+  SY11_REQUIRE((long)B * H * W < (1L << 31), "maxpool5_bwd: too many pixels");
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {dy_ld, dx_ld}, {dy, dx});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
