@@ -55,9 +55,12 @@ const char* sy11_last_error(void);
  *      utils/torch_utils.py:488):
  *   "tune" 0|1            first-call tile autotuner (0: no NEW measurements; recorded / imported picks are still honoured)
  *   "tune_log" 0|1, "igemm_cfg" / "wgrad_cfg" (-1 = automatic, else force one tile configuration), "igemm_korder" 0|1,
- *   "igemm_deep" 0|1|2 (deeper LDS rings), "igemm_bpol" 0|1|2 (cache policy of the filter-row copies).
+ *   "igemm_deep" 0|1|2 (deeper LDS rings), "igemm_bpol" 0|1|2 (cache policy of the filter-row copies),
+ *   "dgrad_s2_halo" 0|1|2 (3x3 stride-2 input gradient in one fused-parity pass: never / where it wins / always),
+ *   "row_map" 0|1 (row walk of the BatchNorm and copy kernels: strided grid of r01 / contiguous chunk per workgroup).
  * Defaults come from the environment (SY11_TUNE, SY11_TUNE_LOG, SY11_IGEMM_CFG, SY11_WGRAD_CFG, SY11_IGEMM_KORDER,
- * SY11_IGEMM_DEEP, SY11_IGEMM_BPOL).  Process-wide; set them between launches, not concurrently with them.
+ * SY11_IGEMM_DEEP, SY11_IGEMM_BPOL, SY11_DGRAD_S2_HALO, SY11_ROW_MAP).  Process-wide; set them between launches, not
+ * concurrently with them.
  * (There is no "deterministic" switch: sums over pixels use f32 atomics in LDS and in HBM — see DESIGN.md §5 for what an
  * ordered mode would take; cfg/default.yaml:29 `deterministic` is therefore NOT honoured.)                              */
 int sy11_set_option(const char* name, int32_t value);
