@@ -390,15 +390,23 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const DwArgs a, int aux_ld, 
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       win[r][0] = zero;
-      win[r][1] = (rok[r] && x0 - 1 >= 0) ? *(const pv*)(rowp[r] + (long)(x0 - 1) * src_ld) : zero;
-      win[r][2] = rok[r] ? *(const pv*)(rowp[r] + (long)x0 * src_ld) : zero;
+      // loads are unconditional from a clamped (always legal) address and masked afterwards: a predicated load compiles to a branch with
+      // a full wait at its join, i.e. three serialised memory latencies per pixel step (r02, tools/dw_micro.py: 84.7 -> 79 us forward,
+      // 59 -> 55 us input gradient on 80x80x128)
+      const pv l1 = *(const pv*)(rowp[r] + (long)max(x0 - 1, 0) * src_ld);
+      const pv l2 = *(const pv*)(rowp[r] + (long)x0 * src_ld);
+      win[r][1] = (rok[r] && x0 - 1 >= 0) ? l1 : zero;
+      win[r][2] = rok[r] ? l2 : zero;
     }
     for (int x = x0; x < x1; ++x) {
+      pv nxt[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) nxt[r] = *(const pv*)(rowp[r] + (long)min(x + 1, W - 1) * src_ld);
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         win[r][0] = win[r][1];
         win[r][1] = win[r][2];
-        win[r][2] = (rok[r] && x + 1 < W) ? *(const pv*)(rowp[r] + (long)(x + 1) * src_ld) : zero;
+        win[r][2] = (rok[r] && x + 1 < W) ? nxt[r] : zero;
       }
       const long m = (long)(b * H + oy) * W + x;
       if (MODE == 2) {
@@ -444,14 +452,39 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const DwArgs a, int aux_ld, 
   // the whole walk and are folded once — LDS atomics per run were 3x the cost of the walk itself
   const int my_c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpv) * VEC;
   if (MODE == 0 && a.stat_sum) {
+    // every thread parks its 2 x VEC partial sums in LDS, then one thread per (sum, channel) adds the 256 / cpv rows that share the
+    // channel: LDS atomics serialise the 16 threads of a channel (r02: 79 -> 64 us on 80x80x128, 33 -> 28 on 20x20x512)
+    float* park = red + 2 * C;                                  // [256][2 * VEC]
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { atomicAdd(&red[my_c + i], s1[i]); atomicAdd(&red[C + my_c + i], s2[i]); }
+    for (int i = 0; i < VEC; ++i) { park[threadIdx.x * 2 * VEC + i] = s1[i]; park[threadIdx.x * 2 * VEC + VEC + i] = s2[i]; }
+    __syncthreads();
+    const int share = 256 / cpv;                                // threads per channel vector (256 % cpv == 0)
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+      const int which = e / C, ch = e - which * C, cvv = ch / VEC, i = ch - cvv * VEC;
+      float tsum = 0.f;                                         // thread t holds channel vector t % cpv (256 % cpv == 0)
+      for (int k = 0; k < share; ++k) tsum += park[(cvv + k * cpv) * 2 * VEC + which * VEC + i];
+      red[e] = tsum;
+    }
   }
   if (MODE == 2) {
+    // three taps at a time through a [256][3 * VEC] parking area (see MODE 0): red[t][c] = sum over the threads of channel c
+    float* park = red + 9 * C;
+    const int share = 256 / cpv;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t3 = 0; t3 < 3; ++t3) {
+      if (t3) __syncthreads();
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) atomicAdd(&red[t * C + my_c + i], gacc[t][i]);
+      for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) park[threadIdx.x * 3 * VEC + tt * VEC + i] = gacc[t3 * 3 + tt][i];
+      __syncthreads();
+      for (int e = threadIdx.x; e < 3 * C; e += 256) {
+        const int tt = e / C, ch = e - tt * C, cvv = ch / VEC, i = ch - cvv * VEC;
+        float tsum = 0.f;
+        for (int k = 0; k < share; ++k) tsum += park[(cvv + k * cpv) * 3 * VEC + tt * VEC + i];
+        red[(t3 * 3 + tt) * C + ch] = tsum;
+      }
+    }
   }
   if (MODE == 0 && a.stat_sum) {
     __syncthreads();
@@ -545,7 +578,7 @@ static int dwconv_fwd_tail(const sy11_conv_desc* d, const void* x, const void* w
   if (dw3x3_ok(d, vec)) {
     int run, rpr; unsigned g;
     dw3x3_geom(d, a.cpv, &run, &rpr, &g, 1024);               // every workgroup ends with 2*C statistic atomics
-    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 0>), dim3(g), dim3(256), 2 * d->C * sizeof(float), st, a, 0,
+    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 0>), dim3(g), dim3(256), (2 * d->C + 256 * 2 * (16 / (int)sizeof(T))) * sizeof(float), st, a, 0,
                                                          (float*)nullptr, run, rpr, tail));
     SY11_LAUNCH_CHECK("dwconv_fwd");
     *tail_done = tail.ticket != nullptr && stat_sum != nullptr;
@@ -593,12 +626,14 @@ extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, cons
   int rc = dw_setup(d, a, vec, x, d->x_ld, dy, dy_ld, (long)d->B * d->OH * d->OW, 32, grid);
   if (rc) return rc;
   a.x = x; a.y = (void*)dy;
-  static int win_wgrad = -1;                                  // r01: the windowed walk wins for fwd / dgrad (148 -> 58 us) but not here
-  if (win_wgrad < 0) { const char* e = getenv("SY11_DW_WINDOW_WGRAD"); win_wgrad = e ? atoi(e) : 0; }
+  // the windowed walk (3 loads per pixel instead of 9) also wins here since its 9 x VEC partial sums per thread are folded through a
+  // parking area instead of LDS atomics (r02, tools/dw_micro.py: 75 -> 64 us on 80x80x128, 51 -> 42 on 40x40x256, 32 -> 22 on 20x20x256)
+  static int win_wgrad = -1;
+  if (win_wgrad < 0) { const char* e = getenv("SY11_DW_WINDOW_WGRAD"); win_wgrad = e ? atoi(e) : 1; }
   if (win_wgrad && dw3x3_ok(d, vec)) {
     int run, rpr; unsigned g;
     dw3x3_geom(d, a.cpv, &run, &rpr, &g, 512);                // every workgroup ends with 9*C filter-gradient atomics
-    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 2>), dim3(g), dim3(256), 9 * d->C * sizeof(float), st, a, dy_ld, dw,
+    SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 2>), dim3(g), dim3(256), (9 * d->C + 256 * 3 * (16 / (int)sizeof(T))) * sizeof(float), st, a, dy_ld, dw,
                                                          run, rpr, BnTailDev{}));
     SY11_LAUNCH_CHECK("dwconv_wgrad");
     return SY11_OK;
