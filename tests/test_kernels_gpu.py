@@ -301,6 +301,47 @@ def test_batchnorm_silu_fwd_bwd(Cn, silu, dtype):
     close(to_nchw(dyv), yr.grad, dtype, "bn dy", mult=6)
 
 
+@pytest.mark.parametrize("row_map", [0, 1])
+@pytest.mark.parametrize("Cn,B,H,W,slots", [(136, 3, 37, 41, 8), (2056, 2, 9, 11, 1), (24, 5, 61, 67, 8), (64, 16, 80, 80, 8)])
+def test_batchnorm_row_walk(Cn, B, H, W, slots, row_map):
+    """The two row walks of the BatchNorm passes (elementwise.hip RowWalk: contiguous chunks / the strided r01 grid) on maps with
+    several workgroups, ragged last chunks, two channel blocks (C = 2056 > 256 vectors) and slotted sums, against fp32 autograd."""
+    from sy11 import _lib
+    o = ops()
+    dtype = torch.float16
+    M = B * H * W
+    y = rnd(B, Cn, H, W, seed=11, scale=1.5)
+    yq = q(y, dtype)
+    gamma, beta = 1 + 0.3 * rnd(Cn, seed=12), 0.2 * rnd(Cn, seed=13)
+    dz = rnd(B, Cn, H, W, seed=14)
+    yr = yq.clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    u = F.batch_norm(yr, None, None, g_, b_, True, 0.03, 1e-3)
+    z = F.silu(u)
+    (z * q(dz, dtype)).sum().backward()
+    f = lambda t: t.to(DEV)
+    yv, dzv = nhwc(y, dtype), nhwc(dz, dtype)
+    ssum = yv.float().sum((0, 1, 2))
+    ssq = (yv.float() ** 2).sum((0, 1, 2))
+    mean, rstd, scale, shift = (torch.empty(Cn, device=DEV) for _ in range(4))
+    o.bn_finalize(M, ssum, ssq, f(gamma), f(beta), 1e-3, 0.03, None, None, mean, rstd, scale, shift)
+    try:
+        _lib.set_option("row_map", row_map)
+        zv = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+        o.bn_act_fwd(yv, scale, shift, zv, silu=True)
+        close(to_nchw(zv), z.detach(), dtype, "bn fwd", mult=2)
+        sg = torch.zeros(2, slots, Cn, device=DEV)
+        o.bn_act_bwd_reduce(yv, dzv, mean, rstd, scale, shift, True, sg[0], sg[1])
+        dyv = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+        dg, db = torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+        o.bn_act_bwd_apply(yv, dzv, mean, rstd, scale, shift, f(gamma), True, sg[0], sg[1], dyv, dg, db)
+    finally:
+        _lib.set_option("row_map", 1)
+    close(db.cpu(), b_.grad, dtype, "dbeta", mult=10)
+    close(dg.cpu(), g_.grad, dtype, "dgamma", mult=10)
+    close(to_nchw(dyv), yr.grad, dtype, "bn dy", mult=6)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_copy_upsample_maxpool(dtype):
     o = ops()
