@@ -110,6 +110,52 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+# Independent sub-graphs on their own streams (the three levels of the Detect head): inside the captured graph they become
+# parallel branches, so the small kernels of the 40x40 / 20x20 levels (200-800 workgroups on 256 CUs) could run beside the 80x80
+# level's instead of after it.  OFF by default: measured r02 (two A/B pairs in one process sequence on one MI355X) 23.11 / 22.88 ms
+# per step with the branches against 22.40 / 22.38 ms on one stream — as with the filter-gradient stream above, parallel branches
+# of a hipGraph cost more than the idle CUs they fill.  SY11_BRANCH_STREAMS=1 turns it on.
+_BRANCH_STREAMS_ON = os.environ.get("SY11_BRANCH_STREAMS", "0") != "0"
+_BRANCH_STREAMS = {}
+
+
+def _branch_stream(device, b):
+    d = torch.device(device)
+    key = (d.index if d.index is not None else torch.cuda.current_device(), b)
+    if key not in _BRANCH_STREAMS:
+        _BRANCH_STREAMS[key] = torch.cuda.Stream(device=d)
+    return _BRANCH_STREAMS[key]
+
+
+class _Branch:
+    """``with ec.branch(b):`` — the enclosed launches (and the tape closures recorded inside) run on branch stream ``b``, ordered
+    after everything the current stream has issued so far.  The caller ends the group with ``ec.join_branches()`` and issues
+    nothing on the main stream in between (that is what makes cross-stream buffer reuse safe: every branch section starts with a
+    wait on the main stream, every consumer on the main stream comes after the join)."""
+
+    def __init__(self, ec, b):
+        self.ec, self.b, self.cm = ec, b, None
+
+    def __enter__(self):
+        ec = self.ec
+        self.start = len(ec.tape)
+        if ec.use_branches:
+            st = _branch_stream(ec.device, self.b)
+            st.wait_stream(torch.cuda.current_stream(ec.device))
+            self.cm = torch.cuda.stream(st)
+            self.cm.__enter__()
+            ec.open_branches.add(self.b)
+        return self
+
+    def __exit__(self, *exc):
+        ec = self.ec
+        if self.cm is not None:
+            self.cm.__exit__(*exc)
+        if ec.use_branches and len(ec.tape) > self.start:
+            ec.tape_branches.append((self.start, len(ec.tape), self.b))
+        return False
+
+
 class Ctx:
     """State of one forward pass through the engine."""
 
@@ -137,6 +183,9 @@ class Ctx:
         self.side = None
         self.side_refs: List = []
         self.use_side = _SIDE_WGRAD and device is not None and torch.device(device).type == "cuda"
+        self.use_branches = _BRANCH_STREAMS_ON and device is not None and torch.device(device).type == "cuda"
+        self.open_branches = set()
+        self.tape_branches: List = []     # (first tape index, end, branch) of the closures recorded inside a branch section
 
     def on_side(self, fn, *keep):
         """Run ``fn`` (kernel launches) on the side stream, ordered after everything issued so far on the current stream.
@@ -161,6 +210,43 @@ class Ctx:
             for fn in self.side_queue:
                 fn()
         self.side_queue = []
+
+    def branch(self, b):
+        return _Branch(self, b)
+
+    def join_branches(self):
+        """The current stream waits for every branch opened since the last join."""
+        if self.open_branches:
+            cur = torch.cuda.current_stream(self.device)
+            for b in sorted(self.open_branches):
+                cur.wait_stream(_branch_stream(self.device, b))
+            self.open_branches.clear()
+
+    def run_tape(self, hi, lo, at=None, then=None):
+        """Backward closures hi, hi-1, ..., lo.  Closures recorded inside a branch section run on that branch's stream again
+        (entered with a wait on the main stream, which has issued nothing since the section's far end); the first main-stream
+        closure after them — and the end of the range — joins.  ``then()`` runs right after closure ``at`` (a main-stream index)."""
+        spans = self.tape_branches
+        for idx in range(hi, lo - 1, -1):
+            b = None
+            for (a0, a1, bb) in spans:
+                if a0 <= idx < a1:
+                    b = bb
+                    break
+            if b is None:
+                self.join_branches()
+                self.tape[idx]()
+            else:
+                st = _branch_stream(self.device, b)
+                if b not in self.open_branches:
+                    st.wait_stream(torch.cuda.current_stream(self.device))
+                    self.open_branches.add(b)
+                with torch.cuda.stream(st):
+                    self.tape[idx]()
+            if idx == at and then is not None:
+                self.join_branches()
+                then()
+        self.join_branches()
 
     def join_side(self):
         if self.side is not None and self.side_refs:
@@ -319,11 +405,10 @@ class EngineFn(torch.autograd.Function):
             a.set_grad(gv)
         hook = module_post_backward.get(id(ec.grads)) if ec.grads is not None else None
         mark = ec.marks.get("bucket") if (hook is not None and getattr(hook, "staged", False)) else None
-        for idx in range(len(ec.tape) - 1, -1, -1):
-            ec.tape[idx]()
-            if idx == mark:                         # every closure of the layers >= the split layer has run: their parameter
-                ec.join_side()                      # gradients are final -> the data-parallel hook may start reducing them
-                hook(ec.grads, 0)
+        def first_bucket():                         # every closure of the layers >= the split layer has run: their parameter
+            ec.join_side()                          # gradients are final -> the data-parallel hook may start reducing them
+            hook(ec.grads, 0)
+        ec.run_tape(len(ec.tape) - 1, 0, mark, first_bucket if mark is not None else None)
         ec.join_side()
         ec.tape.clear()
         ctx.module.__dict__["_sy11_pool_hint"] = ec.pool_need       # next step: one pooled allocation
@@ -395,8 +480,7 @@ class _Graphed:
                 for a, g in zip(self.outs, self.static_gout):
                     if a.data.dim() == 4:
                         a.set_grad(g)
-                for idx in range(len(ec.tape) - 1, (mark if mark is not None else 0) - 1, -1):
-                    ec.tape[idx]()
+                ec.run_tape(len(ec.tape) - 1, mark if mark is not None else 0)
                 ec.join_side()                                      # the wgrad branch joins inside the captured graph
                 if mark is None:
                     self.static_gin = [a.grad_read().permute(0, 3, 1, 2) if a.req else None for a in acts]
@@ -405,8 +489,7 @@ class _Graphed:
                 # between the two replays and run beside this one
                 self.g_bwd2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_bwd2, pool=self.g_fwd.pool(), stream=side, capture_error_mode=_CAPTURE_MODE):
-                    for idx in range(mark - 1, -1, -1):
-                        ec.tape[idx]()
+                    ec.run_tape(mark - 1, 0)
                     ec.join_side()
                     self.static_gin = [a.grad_read().permute(0, 3, 1, 2) if a.req else None for a in acts]
             ec.tape.clear()

@@ -88,12 +88,14 @@ class Detect(nn.Module):
         if self.end2end:
             raise ops._lib.Sy11Error("end2end (v10) heads are outside the hot path")
         maps = []
-        for i in range(self.nl):
-            B, H, W, _ = xs[i].shape
-            m = Act(ec.empty(B, H, W, self.no, dtype=torch.float32))      # logits stay f32 (loss / decode)
-            self._branch(ec, self.cv2[i], xs[i], m.slice(0, 4 * self.reg_max))
-            self._branch(ec, self.cv3[i], xs[i], m.slice(4 * self.reg_max, self.no))
-            maps.append(m)
+        for i in range(self.nl):                                # the levels are independent: one stream (graph branch) each
+            with ec.branch(i):
+                B, H, W, _ = xs[i].shape
+                m = Act(ec.empty(B, H, W, self.no, dtype=torch.float32))      # logits stay f32 (loss / decode)
+                self._branch(ec, self.cv2[i], xs[i], m.slice(0, 4 * self.reg_max))
+                self._branch(ec, self.cv3[i], xs[i], m.slice(4 * self.reg_max, self.no))
+                maps.append(m)
+        ec.join_branches()
         if ec.training:
             return maps
         if self.reg_max != 16:
