@@ -853,17 +853,27 @@ __global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a, const BnTa
         const int k = 8 * half + 16 * g + i;
         wf[nt][g][i] = k < 27 ? StemMma<T>::bits(ElemTraits<T>::to_f(((const T*)a.w)[(nt * 32 + col) * 27 + k])) : (short)0;
       }
-  StemTap tap[16];
+  // per reduction slot: element offset of the tap and a packed (dy + 1) | (dx + 1) << 2 | ok << 4 — two registers per slot, so that
+  // BOTH 32-pixel groups of a wave can have their 16 gathers in flight at once (r02: one group at a time = two exposed memory
+  // round trips per wave at 3 waves per SIMD)
+  int toff[16], tpk[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) tap[j] = stem_tap(8 * half + 16 * (j >> 3) + (j & 7), a);
+  for (int j = 0; j < 16; ++j) {
+    const StemTap t = stem_tap(8 * half + 16 * (j >> 3) + (j & 7), a);
+    toff[j] = t.off;
+    tpk[j] = (t.dy + 1) | ((t.dx + 1) << 2) | ((t.ok ? 1 : 0) << 4);
+  }
   const int M = a.B * a.OH * a.OW;
   const long plane3 = 3L * a.IH * a.IW;
   const bool silu = a.flags & SY11_EPI_SILU;
   float s1[NT], s2[NT], bias_v[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = s2[nt] = 0.f; bias_v[nt] = a.bias ? a.bias[nt * 32 + col] : 0.f; }
-#pragma unroll 1
-  for (int gi = wave * 2; gi < wave * 2 + 2; ++gi) {
+  float raw[2][16];
+  unsigned inmask[2];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    const int gi = wave * 2 + gq;
     const int m = blockIdx.x * 256 + gi * 32 + col;
     const bool ok = m < M;
     // the group's first pixel is wave-uniform: decode it on the scalar unit, then walk `col` pixels with multiply-shift wraps
@@ -878,15 +888,24 @@ __global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a, const BnTa
     const int b = min(b0 + wq2, a.B - 1);
     const int iy0 = oy * a.SH, ix0 = ox * a.SW;
     const float* xb = a.x + b * plane3 + (long)iy0 * a.IW + ix0;
-    ss16x8 af[2];
+    unsigned msk = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       // unconditional load from a clamped (always legal) address + select: a predicated load per slot compiles to 16
       // branch-and-wait sequences, i.e. 16 serialised memory latencies per 32 pixels (r01 ISA inspection)
-      const bool in = ok && tap[j].ok && (unsigned)(iy0 + tap[j].dy) < (unsigned)a.IH && (unsigned)(ix0 + tap[j].dx) < (unsigned)a.IW;
-      const float v = xb[in ? tap[j].off : 0];
-      af[j >> 3][j & 7] = StemMma<T>::bits(in ? v : 0.f);
+      const int dy = (tpk[j] & 3) - 1, dx = ((tpk[j] >> 2) & 3) - 1;
+      const bool in = ok && (tpk[j] & 16) && (unsigned)(iy0 + dy) < (unsigned)a.IH && (unsigned)(ix0 + dx) < (unsigned)a.IW;
+      raw[gq][j] = xb[in ? toff[j] : 0];
+      msk |= (in ? 1u : 0u) << j;
     }
+    inmask[gq] = msk;
+  }
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    const int gi = wave * 2 + gq;
+    ss16x8 af[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) af[j >> 3][j & 7] = StemMma<T>::bits(((inmask[gq] >> j) & 1u) ? raw[gq][j] : 0.f);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       f32x16 acc;
@@ -948,6 +967,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* d
   const int m0 = blockIdx.x * pix_per_block, m1 = min(M, m0 + pix_per_block);
   const StemTap tap = stem_tap(col, a);
   const long plane3 = 3L * a.IH * a.IW;
+  const long tap_plane = (long)tap.off - ((long)tap.dy * a.IW + tap.dx);     // = c * IH * IW of this lane's reduction column
   f32x16 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -972,6 +992,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* d
       const int pw = __builtin_amdgcn_readfirstlane(min(p0, M - 1));        // wave-uniform: scalar division
       const int q = pw / a.OW;
       int ox = pw - q * a.OW + 8 * half, oy = q % a.OH, b = q / a.OH;
+      // all 16 gathers are issued before the first value is used (two loops: addresses + loads, then packing).  Each load is
+      // unconditional, from CLAMPED coordinates (always a legal address), and only the value is selected: `x[in ? idx : 0]`
+      // compiled to 16 exec-masked branches per chunk, and packing inside the load loop to a full wait after every load (r02 ISA)
+      float raw[16];
+      unsigned inmask = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (j == 8) ox += 16;                         // slots 8..15 are pixels 16 + 8*half + (0..7)
@@ -981,13 +1006,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* d
         int oyy = oy + q;
         const int q2 = (int)(((unsigned)oyy * a.mag_oh) >> 20);
         oyy -= q2 * a.OH;
-        const int bb = b + q2;
+        const int bb = min(b + q2, a.B - 1);
         const int pj = p0 + 8 * half + 16 * (j >> 3) + (j & 7);
-        const int iy0 = oyy * a.SH, ix0 = oxx * a.SW;
-        const bool in = pj < m1 && tap.ok && (unsigned)(iy0 + tap.dy) < (unsigned)a.IH && (unsigned)(ix0 + tap.dx) < (unsigned)a.IW;
-        const float v = a.x[in ? bb * plane3 + (long)iy0 * a.IW + ix0 + tap.off : 0];      // clamped address + select: no branches
-        bf[j >> 3][j & 7] = StemMma<T>::bits(in ? v : 0.f);
+        const int iy = oyy * a.SH + tap.dy, ix = oxx * a.SW + tap.dx;
+        const bool in = pj < m1 && tap.ok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+        raw[j] = a.x[bb * plane3 + tap_plane + (long)cy * a.IW + cx];
+        inmask |= (in ? 1u : 0u) << j;
       }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bf[j >> 3][j & 7] = StemMma<T>::bits(((inmask >> j) & 1u) ? raw[j] : 0.f);
     }
     __syncthreads();
 #pragma unroll
