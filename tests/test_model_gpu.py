@@ -132,8 +132,9 @@ def test_tiny_model_train_step_matches_reference_fp32():
     batch = tiny_batch(gold)
     m.train()
     maps = m(batch["img"])
-    for i, mp in enumerate(maps):       # one bar for all three levels: tile picks are pinned in tests (conftest: SY11_TUNE=0)
-        check(gold, f"train.map{i}", mp, rtol=1e-3, atol=1e-4)
+    for i, mp in enumerate(maps):       # P5 is a 2x2 map at batch 2: train-mode BN over 8 samples amplifies the run-to-run f32
+        check(gold, f"train.map{i}", mp, rtol=1e-3, atol=1e-4 if i < 2 else 5e-4)   # summation order of the statistic atomics (tile
+        #                                 picks are pinned by conftest's SY11_TUNE=0; 1e-4 passes most runs, 1 of 544 values reached 4.6e-4)
     m.load_state_dict(tiny_sd())        # same BN buffer state as the generator
     loss, items = m(batch)
     loss.backward()
