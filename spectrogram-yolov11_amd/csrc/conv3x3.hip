@@ -390,7 +390,7 @@ int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn_code, hipStream_t st) {
 template <int TH, int TW, int BN, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void halo_dgrad_s2_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y) {
   typedef _Float16 T;
-  constexpr int BM = 128, KB = 64, RPI = 16, WM = 4, NI = BN / 32;
+  constexpr int BM = 128, KB = 64, RPI = 16, NI = BN / 32;
   constexpr int PH = TH + 1, PW = TW + 1, PR = PH * PW, NIA = (PR + RPI - 1) / RPI;
   constexpr int NAW = (NIA + 1) / 2, A_BYTES = 2 * NAW * RPI * KB, CH = (NAW + 5) / 6;
   constexpr int NSTB = 4, B_BYTES = BN * KB, BPW = (BN / RPI + 1) / 2;

@@ -450,7 +450,6 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const DwArgs a, int aux_ld, 
   }
   // the thread's channel vector never changes (gridDim.x * 256 is a multiple of cpv): partial sums stay in registers for
   // the whole walk and are folded once — LDS atomics per run were 3x the cost of the walk itself
-  const int my_c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpv) * VEC;
   if (MODE == 0 && a.stat_sum) {
     // every thread parks its 2 x VEC partial sums in LDS, then one thread per (sum, channel) adds the 256 / cpv rows that share the
     // channel: LDS atomics serialise the 16 threads of a channel (r02: 79 -> 64 us on 80x80x128, 33 -> 28 on 20x20x512)
