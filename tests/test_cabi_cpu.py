@@ -57,6 +57,22 @@ def test_error_codes_and_messages_without_gpu():
         _lib.check(-1, "x")
 
 
+def test_run_time_options_round_trip_and_reject_unknown_names():
+    """Every option include/sy11.h documents can be set and read back without a GPU; an unknown name is an error, not a no-op."""
+    from sy11 import _lib
+    lib = _lib.load()
+    names = re.findall(r'"([a-z0-9_]+)"', HEADER[HEADER.index("run-time options"):HEADER.index("int sy11_set_option")])
+    assert {"tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder", "igemm_deep", "igemm_bpol", "dgrad_s2_halo", "row_map"} <= set(names)
+    for n in set(names) - {"deterministic"}:
+        old = _lib.get_option(n)
+        try:
+            _lib.set_option(n, 1)
+            assert _lib.get_option(n) == 1, n
+        finally:
+            _lib.set_option(n, old)
+    assert lib.sy11_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.sy11_last_error()
+
+
 def test_product_fails_loudly_on_cpu_tensors():
     import torch
     from sy11 import _lib
