@@ -56,7 +56,7 @@ const char* sy11_last_error(void);
  *   "tune" 0|1            first-call tile autotuner (0: no NEW measurements; recorded / imported picks are still honoured)
  *   "tune_log" 0|1, "igemm_cfg" / "wgrad_cfg" (-1 = automatic, else force one tile configuration), "igemm_korder" 0|1,
  *   "igemm_deep" 0|1|2 (deeper LDS rings), "igemm_bpol" 0|1|2 (cache policy of the filter-row copies),
- *   "dgrad_s2_halo" 0|1|2 (3x3 stride-2 input gradient in one fused-parity pass: never / where it wins / always),
+ *   "dgrad_s2_halo" 0|1 (3x3 stride-2 input gradient: four igemm launches, one per output parity / ONE fused-parity pass),
  *   "row_map" 0|1 (row walk of the BatchNorm and copy kernels: strided grid of r01 / contiguous chunk per workgroup).
  * Defaults come from the environment (SY11_TUNE, SY11_TUNE_LOG, SY11_IGEMM_CFG, SY11_WGRAD_CFG, SY11_IGEMM_KORDER,
  * SY11_IGEMM_DEEP, SY11_IGEMM_BPOL, SY11_DGRAD_S2_HALO, SY11_ROW_MAP).  Process-wide; set them between launches, not

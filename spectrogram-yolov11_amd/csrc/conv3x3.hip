@@ -388,7 +388,7 @@ int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn_code, hipStream_t st) {
 // written as whole contiguous pixel rows of the 2TH x 2TW block.  Same machinery as halo3x3_kernel otherwise.
 //   class (py, px) of dx pixel (2Y+py, 2X+px):  py = 0: filter row r = 1 (dy row Y);  py = 1: r = 0 (dy row Y+1) and r = 2 (dy row Y).
 template <int TH, int TW, int BN, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void halo_dgrad_s2_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void halo_dgrad_s2_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y) {
   typedef _Float16 T;
   constexpr int BM = 128, KB = 64, RPI = 16, NI = BN / 32;
   constexpr int PH = TH + 1, PW = TW + 1, PR = PH * PW, NIA = (PR + RPI - 1) / RPI;
@@ -578,10 +578,7 @@ bool sy11_halo_dgrad_s2_legal(const IgemmArgs& a) {
 template <int TH, int TW>
 static void halo_dgrad_s2_tile(const IgemmArgs& a, int bn, bool accum, dim3 grid, hipStream_t st, int tx, int ty) {
   dim3 block(256);
-  if (bn == 128) {
-    if (accum) hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 128, 8>), grid, block, 0, st, a, tx, ty);
-    else hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 128, 0>), grid, block, 0, st, a, tx, ty);
-  } else if (bn == 64) {
+  if (bn == 64) {
     if (accum) hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 64, 8>), grid, block, 0, st, a, tx, ty);
     else hipLaunchKernelGGL((halo_dgrad_s2_kernel<TH, TW, 64, 0>), grid, block, 0, st, a, tx, ty);
   } else {
@@ -595,7 +592,9 @@ int sy11_halo_dgrad_s2_launch(const IgemmArgs& a_in, hipStream_t st) {
   IgemmArgs a = a_in;
   int th, tw;
   halo_tile(a.IW, a.IH, 0, &th, &tw);
-  const int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  // 64-wide channel tiles even for 128+ channels: 196 VGPRs = TWO workgroups per CU, which beats one 128-wide tile per CU that
+  // loads the dy patch half as often (r02, tools/dgrad_s2_micro.py: 160x160x128 <- 80x80x128 266 -> 218 us, 80x80x256 <- 40x40x256 227 -> 186)
+  const int bn = a.N > 32 ? 64 : 32;
   const int B = a.M;                                  // the caller passes the batch size in M
   const int tx = cdiv(a.IW, tw), ty = cdiv(a.IH, th);
   a.tiles_n = cdiv(a.N, bn);

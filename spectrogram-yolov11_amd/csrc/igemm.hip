@@ -825,11 +825,10 @@ extern "C" int sy11_conv2d_dgrad(const sy11_conv_desc* d, const void* dy, int32_
   SY11_REQUIRE(!(d->flags & (SY11_EPI_SILU | SY11_EPI_OUT_F32)), "conv2d_dgrad: only SY11_EPI_ACCUM is meaningful");
   // 3x3 / stride 2 / pad 1 in f16: all four parity classes in ONE pass over dy (conv3x3.hip halo_dgrad_s2_kernel), unless switched off
   if (d->dtype == SY11_F16 && d->KH == 3 && d->KW == 3 && d->SH == 2 && d->SW == 2 && d->PH == 1 && d->PW == 1 && d->DH == 1 && d->DW == 1 &&
-      sy11_opt(OPT_IGEMM_CFG) < 0 && (sy11_opt(OPT_DGRAD_S2_HALO) == 2 || (sy11_opt(OPT_DGRAD_S2_HALO) == 1 && (d->C <= 64 || (!(d->flags & SY11_EPI_ACCUM) && d->N <= d->C && d->C <= 256))))) {
-    // default (1): where dx has <= 64 channels (320x320x32 <- 160x160x64: 402 -> 182 us, accumulating 520 -> 251), or a plain store of
-    // <= 256 channels with dy no wider than dx (160x160x128 <- 80x80x128: 274 -> 259 us).  Elsewhere the four tuned igemm launches
-    // win: accumulating into 128+ channels (448 vs 493, 284 vs 307, 107 vs 119 us — one workgroup per CU cannot hide the reads of dx),
-    // four channel tiles per dy patch (40x40x512 <- 20x20x512: 176 vs 213 us), dy twice as wide as dx.  2 = always (tests).
+      sy11_opt(OPT_IGEMM_CFG) < 0 && sy11_opt(OPT_DGRAD_S2_HALO) != 0) {
+    // yolo11s at batch 64, plain / accumulating (tools/dgrad_s2_micro.py): 320x320x32 <- 160x160x64 394 -> 168 / 519 -> 220 us,
+    // 160x160x128 <- 80x80x128 278 -> 218 / 427 -> 312, 80x80x256 <- 40x40x256 219 -> 186 / 261 -> 209, 40x40x256 <- 20x20x512
+    // 104 -> 94 / 112 -> 101, the head's 80x80x128 87 -> 62 / 103 -> 77 and 40x40x256 72 -> 55 / 83 -> 63.  0 = the four igemm launches.
     IgemmArgs a{};
     a.x = dy; a.w = wt; a.y = dx;
     a.C = d->N; a.wK = 9 * d->N; a.N = d->C; a.K = 9 * d->N; a.T = 9;
