@@ -118,8 +118,11 @@ def pack_targets(batch_idx, cls, bboxes, batch_size, scale):
     return out
 
 
-def detection_loss(maps, batch, nc, strides=(8.0, 16.0, 32.0), box=7.5, cls_gain=0.5, dfl=1.5, return_targets=False):
-    """v8DetectionLoss.__call__: returns (sum(loss)·B, detached [box, cls, dfl])."""
+def detection_loss(maps, batch, nc, strides=(8.0, 16.0, 32.0), box=7.5, cls_gain=0.5, dfl=1.5, return_targets=False, pinned=None):
+    """v8DetectionLoss.__call__: returns (sum(loss)·B, detached [box, cls, dfl]).
+    ``pinned`` = a (t_labels, t_boxes, t_scores, fg, gt_idx) tuple from an earlier call: the task-aligned assignment (a
+    no-grad, DISCRETE function of the predictions, loss.py:250-258) is taken from there instead of being recomputed — used
+    by the 16-bit parity tests so that both sides differentiate the same smooth function."""
     B = maps[0].shape[0]
     no = nc + 4 * REG_MAX
     cat = torch.cat([m.reshape(B, no, -1) for m in maps], 2)
@@ -135,9 +138,12 @@ def detection_loss(maps, batch, nc, strides=(8.0, 16.0, 32.0), box=7.5, cls_gain
     proj = torch.arange(REG_MAX, dtype=torch.float32)
     pred_ltrb = pred_dist.view(B, a, 4, REG_MAX).softmax(3).matmul(proj)
     pred_bboxes = dist2bbox(pred_ltrb, anchors, xywh=False)
-    t_labels, t_boxes, t_scores, fg, gt_idx = tal_assign(
-        pred_scores.detach().sigmoid(), (pred_bboxes.detach() * stride_t), anchors * stride_t,
-        gt_labels, gt_bboxes, mask_gt, nc=nc)
+    if pinned is not None:
+        t_labels, t_boxes, t_scores, fg, gt_idx = pinned
+    else:
+        t_labels, t_boxes, t_scores, fg, gt_idx = tal_assign(
+            pred_scores.detach().sigmoid(), (pred_bboxes.detach() * stride_t), anchors * stride_t,
+            gt_labels, gt_bboxes, mask_gt, nc=nc)
     tss = max(t_scores.sum(), 1)
     loss = torch.zeros(3)
     loss[1] = F.binary_cross_entropy_with_logits(pred_scores, t_scores.to(pred_scores.dtype), reduction="none").sum() / tss

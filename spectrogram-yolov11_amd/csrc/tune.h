@@ -58,6 +58,10 @@ Cache& cache(int kind);
 // nothing could be measured.
 template <class F>
 int pick(const int* cands, int ncand, F&& run, hipStream_t st, const char* what, const int* key, int nkey) {
+  // one measurement at a time per process: the event pair is shared, and two threads timing candidates concurrently would also
+  // time each other's kernels (the library's only other process-wide state is the option table and the pick tables, core.hip)
+  static std::mutex mu;
+  std::lock_guard<std::mutex> guard(mu);
   static hipEvent_t e0 = nullptr, e1 = nullptr;
   if (!e0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) { (void)hipGetLastError(); return -1; }
   int best = -1;

@@ -486,7 +486,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
     const uint64_t h = sy11tune::hash(key, (int)(sizeof(key) / sizeof(int)));
     int hit;
     if (cache.get(h, &hit)) {
-      cfg = hit;
+      if (hit >= 0 && hit < ncfg) cfg = hit;          // an imported record from another build / a corrupt file: keep the heuristic
     } else if (sy11tune::enabled() && !sy11tune::capturing(st)) {
       const size_t need = (size_t)a.N * a.K;
       if (need > scratch_elems) {                       // candidates accumulate with atomics: measure into a scratch dW

@@ -40,6 +40,18 @@ class _InertHolder(nn.Module):
         raise _lib.Sy11Error(f"{type(self).__name__} is a checkpoint placeholder: the criterion runs as sy11.utils.loss.v8DetectionLoss")
 
 
+class BboxLoss(_InertHolder):
+    """ultralytics.utils.loss.BboxLoss placeholder (module level: instances stay picklable)."""
+
+
+class DFLoss(_InertHolder):
+    """ultralytics.utils.loss.DFLoss placeholder."""
+
+
+class TaskAlignedAssigner(_InertHolder):
+    """ultralytics.utils.tal.TaskAlignedAssigner placeholder."""
+
+
 def _class_table():
     from ..nn import tasks
     from ..nn.modules import block, conv, head
@@ -54,10 +66,11 @@ def _class_table():
     t[("ultralytics.utils", "IterableSimpleNamespace")] = IterableSimpleNamespace
     # a reference model pickled after its first loss call carries `criterion` (v8DetectionLoss with its BboxLoss / DFLoss /
     # TaskAlignedAssigner children).  None of that state is used here — the criterion is rebuilt by init_criterion() — so the
-    # children unpickle into inert holders and `criterion` is dropped by load_checkpoint's caller on first use.
+    # children unpickle into the inert holders above and `_adopt` drops `criterion` from every loaded model.
     t[("ultralytics.utils.loss", "v8DetectionLoss")] = loss.v8DetectionLoss
-    for mod, n in (("ultralytics.utils.loss", "BboxLoss"), ("ultralytics.utils.loss", "DFLoss"), ("ultralytics.utils.tal", "TaskAlignedAssigner")):
-        t[(mod, n)] = type(n, (_InertHolder,), {})
+    t[("ultralytics.utils.loss", "BboxLoss")] = BboxLoss
+    t[("ultralytics.utils.loss", "DFLoss")] = DFLoss
+    t[("ultralytics.utils.tal", "TaskAlignedAssigner")] = TaskAlignedAssigner
     return t
 
 
@@ -87,6 +100,9 @@ def _adopt(model: nn.Module) -> nn.Module:
     the per-filter group tag the engine keeps, no stale engine caches."""
     from ..nn.modules.conv import Conv
     model = model.float()
+    # a criterion pickled by the reference carries the reference's attributes, not this build's (stride_f, _gains ...):
+    # drop it, BaseModel.loss rebuilds it on first use
+    model.__dict__.pop("criterion", None)
     for m in model.modules():
         for k in [k for k in m.__dict__ if k.startswith("_sy11_")]:
             del m.__dict__[k]

@@ -38,6 +38,11 @@ def allreduce_flat(flat: torch.Tensor, group=None):
     return flat
 
 
+# The two-bucket overlap below has only ever run over gloo (both ranks on one GPU, tests/test_ddp_gpu.py) — there the collective
+# does not run on its own device stream, so the concurrent case (RCCL reducing the `late` ranges while the second backward graph
+# replays) is UNVERIFIED on hardware.  Until a >= 2-GPU RCCL run of tests/test_ddp_nccl_gpu.py has been recorded it is opt-in
+# (SY11_DDP_OVERLAP=1); the default is ONE all-reduce of the flat buffer after backward: 37.8 MB over xGMI ~ 0.3 ms of a ~22 ms step.
+OVERLAP = os.environ.get("SY11_DDP_OVERLAP", "0") != "0"
 BUCKET_LAYER = 5      # layers >= 5 of the yolo11 graph hold > 99 % of the parameters; layers 0-4 (320^2 ... 80^2 maps) a third of the backward time
 
 
@@ -88,6 +93,7 @@ class _StagedAllReduce:
         if getattr(s, "defer_allreduce", False):
             return
         if stage == 0:
+            self.works, self.stage0_done = [], False                  # a backward that raised between the stages leaves nothing behind
             if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
                 return
             self._ranges()
@@ -114,7 +120,7 @@ class _StagedAllReduce:
         self.works, self.stage0_done = [], False
 
 
-def attach(model: torch.nn.Module, group=None, bucket_layer=BUCKET_LAYER):
+def attach(model: torch.nn.Module, group=None, bucket_layer=None):
     """Make every engine backward of ``model`` end with the gradient sum over ranks (no-op for world_size 1), the first
     bucket overlapped with the rest of backward when the model is a layer graph (BaseModel)."""
     store = model.__dict__.get("_sy11_grads")
@@ -124,6 +130,8 @@ def attach(model: torch.nn.Module, group=None, bucket_layer=BUCKET_LAYER):
     # gradient accumulation (accumulate > 1): the flat buffer sums the micro-steps, so it must be reduced ONCE, after the
     # last backward of the window (the trainer raises ``store.defer_allreduce`` on the others) — reducing it after every
     # backward would re-sum the already reduced part.  SUM is linear: allreduce(sum_k g_k) == sum_k allreduce(g_k).
+    if bucket_layer is None:
+        bucket_layer = BUCKET_LAYER if OVERLAP else 0
     layers = getattr(model, "model", None)
     if bucket_layer and layers is not None and hasattr(layers, "__len__") and len(layers) > bucket_layer + 1:
         model.__dict__["_sy11_bucket_layer"] = int(bucket_layer)

@@ -159,6 +159,10 @@ class YOLO:
         hist = self.trainer.fit(dl, epochs, val_batches=val_batches, save_dir=save_dir, close_mosaic=close_mosaic, start_epoch=start,
                                 lrf=lrf, cos_lr=cos_lr, patience=patience)
         self.metrics = hist[-1]["metrics"] if hist else None
+        if rank in (-1, 0):                                                      # the per-epoch records (what results.csv holds in the
+            import json                                                          # reference); a launching parent reads them back
+            Path(save_dir).mkdir(parents=True, exist_ok=True)
+            (Path(save_dir) / "results.json").write_text(json.dumps(hist, default=str))
         best = Path(save_dir) / "best.pt"
         if rank in (-1, 0) and best.exists():                                    # engine/model.py:833-837: continue with best.pt
             self.model, self.ckpt = attempt_load_one_weight(str(best), device=dev)
@@ -179,7 +183,7 @@ class YOLO:
         payload = {"pkg": str(Path(__file__).resolve().parents[2]), "model": self.model_name, "nc": getattr(self.model.model[-1], "nc", None),
                    "kw": kw}
         src = ("import json, sys\n"
-               f"P = json.loads({json.dumps(json.dumps(payload))})\n"
+               f"P = json.loads({json.dumps(json.dumps(payload, default=str))})\n"
                "sys.path.insert(0, P['pkg'])\n"
                "from sy11.engine.model import YOLO\n"
                "m = YOLO(P['model'], nc=P['nc']) if str(P['model']).endswith(('.yaml', '.yml')) else YOLO(P['model'])\n"
@@ -196,7 +200,10 @@ class YOLO:
         ck = best if best.exists() else last
         if ck.exists():
             self.model, self.ckpt = attempt_load_one_weight(str(ck), device="cpu")
-        return ck
+        rec = Path(save_dir) / "results.json"
+        hist = json.loads(rec.read_text()) if rec.exists() else []               # same return type as the single-process branch
+        self.metrics = hist[-1]["metrics"] if hist else None
+        return hist
 
     def val(self, data=None, batch=32, imgsz=640, conf=0.001, iou=0.7, half=False, workers=8, **kw):
         """engine/model.py:623-670 -> DetectionValidator over the rect val loader."""
@@ -235,10 +242,17 @@ def _device_list(device):
     """`device=0`, `"0,1"`, `[0, 1]`, `"cuda:1"` -> list of GPU indices (utils/torch_utils.py select_device's parsing)."""
     if device is None or device == "" or str(device) == "cpu":
         return []
-    if isinstance(device, (list, tuple)):
-        return [int(d) for d in device]
-    txt = str(device).lower().replace("cuda:", "").replace("(", "").replace(")", "").replace("[", "").replace("]", "").replace(" ", "")
-    return [int(d) for d in txt.split(",") if d != ""]
+    from .. import _lib
+    try:
+        if isinstance(device, (list, tuple)):
+            return [int(d) for d in device]
+        txt = str(device).lower().replace("cuda:", "").replace("(", "").replace(")", "").replace("[", "").replace("]", "").replace(" ", "")
+        if txt == "cuda":
+            return [0]
+        return [int(d) for d in txt.split(",") if d != ""]
+    except (TypeError, ValueError):
+        raise _lib.Sy11Error(f"device={device!r}: expected 'cpu', a GPU index, 'cuda:N', '0,1' or a list of indices "
+                             f"(the MI355X is the only accelerator this build drives)") from None
 
 
 def _hyp_defaults():

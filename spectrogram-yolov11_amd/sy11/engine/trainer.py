@@ -82,6 +82,7 @@ class DetectionTrainer:
             enable_graphs(self.model)
         self.last_opt_step = -1
         self.ni = 0
+        self._sig_runs = {}                                 # input signature -> training steps seen (tuner-pick sharing, train_step)
 
     @staticmethod
     def build_optimizer(model, name="SGD", lr=0.01, momentum=0.9, decay=1e-5):
@@ -355,6 +356,17 @@ class DetectionTrainer:
             self.optimizer_step()
             self.last_opt_step = self.ni
         self.ni += 1
-        if self.world_size > 1 and self.ni <= 2 and self.device.type == "cuda":
-            ddp.share_tuner_picks()                              # collective; after each of the two eager steps that precede capture
+        if self.world_size > 1 and self.device.type == "cuda":
+            # Rank 0 alone measures tile configurations, and it measures per PROBLEM, on the first eager call that meets it:
+            # the first two steps of every input signature (a new image size, the short last batch of an epoch, the first
+            # steps after a resume) run eagerly and may add picks, the third is captured.  So the tables are shared after each
+            # of those two steps — a rule every rank evaluates identically from its own inputs (the ranks of a data-parallel
+            # job see the same sequence of batch shapes), independent of the global step counter `ni` (which a resumed run
+            # starts at start_epoch * nb).  Ranks >= 1 never measure (`tune` stays 0 there by design).
+            img = batch["img"]
+            sig = (tuple(img.shape), img.dtype, self.model._sy11_dtype)
+            n = self._sig_runs.get(sig, 0) + 1
+            self._sig_runs[sig] = n
+            if n <= 2:
+                ddp.share_tuner_picks()                          # collective
         return loss.detach(), items

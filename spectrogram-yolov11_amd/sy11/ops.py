@@ -430,8 +430,9 @@ class DetLossWorkspace:
         self.sums = self.zero[2 * B * G:].view(64, 4)
 
 
-def det_loss_forward(maps, strides, nc, gt):
-    """maps: contiguous NHWC f32 (B,H,W,64+nc) list; gt (B,G,5).  -> (workspace, sums (64,4) device tensor)."""
+def det_loss_assign(maps, strides, nc, gt):
+    """Stage 1 of the criterion (decode + task-aligned assignment + normalised alignment and its sum `tss`):
+    maps: contiguous NHWC f32 (B,H,W,64+nc) list; gt (B,G,5).  -> workspace holding assign / norm / sums[:, 0]."""
     _need_gpu(*maps, gt)
     for m in maps:
         if m.dtype != torch.float32 or not m.is_contiguous() or m.shape[-1] != 64 + nc:
@@ -440,9 +441,20 @@ def det_loss_forward(maps, strides, nc, gt):
     cast = lambda a: C.cast(a, C.c_void_p)
     call("sy11_det_loss_assign", w.B, nc, w.nl, cast(w.ptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt), _p(w.pbox),
          _p(w.align), _p(w.overlap), _p(w.topk), _p(w.assign), _p(w.pos), _p(w.norm), _p(w.sums), _stream())
-    call("sy11_det_loss_terms", w.B, nc, w.nl, cast(w.ptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt), _p(w.assign),
+    return w
+
+
+def det_loss_terms(w: DetLossWorkspace):
+    """Stage 2: box / cls / dfl partial sums into sums[:, 1:4] for the assignment (w.assign, w.norm) the workspace holds."""
+    cast = lambda a: C.cast(a, C.c_void_p)
+    call("sy11_det_loss_terms", w.B, w.nc, w.nl, cast(w.ptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt), _p(w.assign),
          _p(w.norm), _p(w.sums), _stream())
     return w
+
+
+def det_loss_forward(maps, strides, nc, gt):
+    """maps: contiguous NHWC f32 (B,H,W,64+nc) list; gt (B,G,5).  -> workspace (sums (64,4) = [tss, box, cls, dfl] partials)."""
+    return det_loss_terms(det_loss_assign(maps, strides, nc, gt))
 
 
 def det_loss_backward(w: DetLossWorkspace, upstream_over_tss: torch.Tensor, gains, out=None):

@@ -4,18 +4,23 @@ What is compared: the HIP path in its f16 mode (the reference's AMP dtype, engin
 ``emulate_f16`` — the CPU restatement with the SAME rounding points (16-bit operands and stored activations / gradients,
 f32 accumulation), so the two differ by summation order only, not by the quantisation itself.
 
-Why the model state is "default initialisation + a few hundred f32 SGD steps on the device": at initialisation every anchor
-predicts the same box / class logits (Detect.bias_init), the task-aligned assigner's top-10 is a tie everywhere and flips
-wholesale on last-bit noise — two IDENTICAL f16 runs of the product then differ by 38 % in the gradient (tools/fp16_emu_check.py,
-r02).  A few optimizer steps break the ties; after that two identical runs agree to ~1e-3 and the comparison has power.
-The state is just an input: both sides evaluate the same function at it.
+The criterion is split the way the reference splits it (utils/loss.py:250-258: the task-aligned assignment runs under
+``no_grad`` on detached predictions — a DISCRETE function of the logits — and the loss terms are smooth given its output):
 
-Bars (north_star / VERDICT r01 #1): loss within 2e-3 (absolute bar); whole-gradient relative error within 1e-2, per-tensor
-median within 1e-2, every tensor within 2 % of its norm (+ a floor of 1e-4 of the largest tensor norm) — each of the three
-gradient bars PLUS three times the spread of three identical device runs of the same quantity (per tensor: at least the 90th percentile of all tensors' relative spreads): filters in front of a
-BatchNorm and biases feeding one have an exactly-zero or near-zero true gradient, what is measured there is 16-bit rounding
-noise on the device and in the emulation alike, and how chaotic the pre-trained state is varies from run to run.  Typical
-r02 numbers: yolo11n loss 2e-5, whole gradient 6e-3 (rerun 2.5e-3), median 6e-3; fusion variant 5e-6 / 1.4e-3 (2.2e-3) / 2.3e-3."""
+  1. the ASSIGNMENT is tested on its own, bit-exact: the device's assign stage on the device's own f32 head logits against
+     ``oracle.loss_ref.tal_assign`` on the same logits (copied to the host);
+  2. the LOSS and the GRADIENTS are compared with that one assignment PINNED on both sides (``detection_loss(pinned=...)`` in the
+     oracle, ``assign`` / ``norm`` of the criterion workspace overwritten on the device), so a last-bit difference in a logit can
+     no longer move an anchor across a top-10 boundary on one side only.  One attempt, no retry;
+  3. how many anchors the oracle's OWN logits (16-bit emulation) would have assigned differently is measured and printed: that is
+     the whole effect the r02 retry was hiding (r02 log: one pre-trained state in twelve had the whole gradient 3.4 % apart).
+
+Why the model state is "default initialisation + a few hundred f32 SGD steps on the device": at initialisation every anchor
+predicts the same box / class logits (Detect.bias_init); a trained state is simply a more realistic input.
+
+Bars (north_star / VERDICT r02 #1): loss within 2e-3; whole-gradient relative error within 1e-2, per-tensor median within 1e-2,
+every tensor within 2 % of its norm (+ a floor of 1e-4 of the largest tensor norm: filters in front of a BatchNorm and biases
+feeding one have an exactly-zero true gradient, what is measured there is 16-bit rounding noise on both sides)."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -24,6 +29,8 @@ import torch
 from oracle import loss_ref, yolo11_ref as R
 
 DEV = "cuda"
+GAINS = (7.5, 0.5, 1.5)
+STRIDES = (8.0, 16.0, 32.0)
 
 
 def pretrained_state(cfg, nc, nb, sz, steps, seed=11):
@@ -42,22 +49,49 @@ def pretrained_state(cfg, nc, nb, sz, steps, seed=11):
     return {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
 
 
-def run_f16_parity(cfg, layers, nc, nb=16, sz=256, steps=200, loss_scale=64.0, attempts=2):
-    """Two independently pre-trained states at most: the loss is a DISCRETE function of the predictions (top-10 assignment), and about
-    one state in twelve sits close enough to an assignment boundary that device and oracle land on different sides of it (r02: whole
-    gradient 3.4 % apart with a 0.09 % rerun spread, all other runs 0.2-0.9 %).  A kernel defect fails every state; a boundary state
-    does not repeat."""
-    err = None
-    for k in range(attempts):
-        try:
-            return _run_f16_parity_once(cfg, layers, nc, nb, sz, steps, loss_scale, seed=11 + k)
-        except AssertionError as e:          # noqa: PERF203
-            err = e
-            print(f"f16 parity {cfg}: attempt {k + 1} failed ({str(e)[:120]}) — {'retrying on another state' if k + 1 < attempts else 'giving up'}")
-    raise err
+def oracle_assignment(maps_nchw, batch, nc):
+    """TaskAlignedAssigner outputs (oracle) for head maps given as NCHW f32 CPU tensors."""
+    with torch.no_grad():
+        _, _, tg = loss_ref.detection_loss([m.clone() for m in maps_nchw], batch, nc=nc, return_targets=True)
+    return tg
 
 
-def _run_f16_parity_once(cfg, layers, nc, nb, sz, steps, loss_scale, seed):
+def device_targets(tg, B, A):
+    _, _, t_scores, fg, gt_idx = tg
+    assign = torch.where(fg, gt_idx, torch.full_like(gt_idx, -1)).to(torch.int32).view(B, A)
+    return assign, t_scores.sum(-1).float().view(B, A)
+
+
+def pinned_device_step(m, batch, nc, loss_scale, pin=None):
+    """Forward to the head maps, the criterion stage by stage through the C-ABI wrappers (assignment optionally overwritten by
+    ``pin`` = (assign, norm)), backward through the engine.  -> (loss, gradient dict, f32 head maps on the host, device assign)."""
+    from sy11 import ops as K
+    maps = m(batch["img"].to(DEV))                                        # train mode: the three raw maps, autograd-connected
+    B = maps[0].shape[0]
+    nhwc = [f.permute(0, 2, 3, 1).contiguous() for f in maps]
+    hw = maps[0].shape[2:]
+    scale = torch.tensor([hw[1], hw[0], hw[1], hw[0]], dtype=torch.float32) * STRIDES[0]
+    gt = loss_ref.pack_targets(batch["batch_idx"], batch["cls"], batch["bboxes"], B, scale).to(DEV)
+    w = K.det_loss_assign([t.detach() for t in nhwc], STRIDES, nc, gt)
+    dev_assign = w.assign.clone()
+    if pin is not None:
+        w.assign.copy_(pin[0].to(DEV))
+        w.norm.copy_(pin[1].to(DEV))
+        w.sums.zero_()
+        w.sums[0, 0] = w.norm.sum()
+    K.det_loss_terms(w)
+    tot = w.sums.sum(0)
+    tss = tot[0].clamp(min=1.0)
+    items = tot[1:4] / tss * torch.tensor(GAINS, device=DEV)
+    loss = items.sum() * B
+    up = (torch.full((1,), float(loss_scale), device=DEV) / tss).contiguous()
+    dmaps = K.det_loss_backward(w, up, GAINS)
+    torch.autograd.backward(maps, [d.permute(0, 3, 1, 2) for d in dmaps])
+    grads = {k: p.grad.float().cpu() / loss_scale for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+    return loss.item(), grads, [f.detach().float().cpu() for f in maps], dev_assign.cpu()
+
+
+def run_f16_parity(cfg, layers, nc, nb=16, sz=256, steps=200, loss_scale=64.0, seed=11):
     from sy11.nn.tasks import DetectionModel
     sd = pretrained_state(cfg, nc, nb, sz, steps, seed=seed)
     g = torch.Generator().manual_seed(3)
@@ -66,51 +100,58 @@ def _run_f16_parity_once(cfg, layers, nc, nb, sz, steps, loss_scale, seed):
     batch = {"img": img, "batch_idx": torch.arange(nb).repeat_interleave(2).float(), "cls": torch.randint(0, nc, (n, 1), generator=g).float(),
              "bboxes": torch.cat((0.3 + 0.4 * torch.rand(n, 2, generator=g), 0.15 + 0.4 * torch.rand(n, 2, generator=g)), 1)}
 
-    def device_run():
+    def model():
         m = DetectionModel(cfg, ch=3, nc=nc, verbose=False)
-        m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+        m.args = SimpleNamespace(box=GAINS[0], cls=GAINS[1], dfl=GAINS[2])
         m.load_state_dict(sd)
         m._sy11_dtype = torch.float16
-        m = m.to(DEV).train()
-        loss, items = m({k: v.to(DEV) for k, v in batch.items()})
-        (loss * loss_scale).backward()                      # what GradScaler does: 16-bit gradients need the head room
-        return loss.item(), {k: p.grad.float().cpu() / loss_scale for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+        return m.to(DEV).train()
 
+    # (1) the assignment on its own: device stage vs oracle on the SAME (device) logits — bit-exact
+    _, _, dev_maps, dev_assign = pinned_device_step(model(), batch, nc, loss_scale)
+    tg = oracle_assignment(dev_maps, batch, nc)
+    B, A = dev_assign.shape
+    pin = device_targets(tg, B, A)
+    assert int((pin[0] >= 0).sum()) > 0
+    assert torch.equal(dev_assign, pin[0]), f"{int((dev_assign != pin[0]).sum())} anchors assigned differently on identical logits"
+
+    # (2) loss and gradients with that assignment pinned on both sides
+    l1, g1, _, _ = pinned_device_step(model(), batch, nc, loss_scale, pin)
+    l2, g2, _, _ = pinned_device_step(model(), batch, nc, loss_scale, pin)
     osd = {k: v.clone() for k, v in sd.items()}
     for k, v in osd.items():
         if v.dtype.is_floating_point and "running" not in k and ".dfl." not in k:
             v.requires_grad_(True)
     with R.emulate_f16():
-        maps = R.forward(osd, layers, img, train=True)
-    oloss, _ = loss_ref.detection_loss(maps, batch, nc=nc)
+        omaps = R.forward(osd, layers, img, train=True)
+    oloss, _ = loss_ref.detection_loss(omaps, batch, nc=nc, pinned=tg)
     (oloss * loss_scale).backward()
     og = {k: v.grad / loss_scale for k, v in osd.items() if v.requires_grad and v.grad is not None}
-    (l1, g1), (l2, g2), (l3, g3) = device_run(), device_run(), device_run()
 
-    assert abs(l1 - oloss.item()) <= 2e-3 * abs(oloss.item()), (l1, oloss.item())
+    # (3) what pinning removed: anchors the oracle's own (emulated 16-bit) logits would assign differently
+    own = device_targets(oracle_assignment([t.detach() for t in omaps], batch, nc), B, A)
+    flips = int((own[0] != pin[0]).sum())
+    n_fg = int((pin[0] >= 0).sum())
+
+    loss_rel = abs(l1 - oloss.item()) / abs(oloss.item())
     keys = [k for k in g1 if k in og]
     assert len(keys) >= 0.95 * len(og)
     fa, fb = torch.cat([g1[k].flatten() for k in keys]), torch.cat([og[k].flatten() for k in keys])
     whole = (fa - fb).norm().item() / fb.norm().item()
-    cos = torch.dot(fa, fb).item() / (fa.norm().item() * fb.norm().item())
+    cos = torch.dot(fa.double(), fb.double()).item() / (fa.double().norm().item() * fb.double().norm().item())
     fc = torch.cat([g2[k].flatten() for k in keys])
-    whole_noise = (fa - fc).norm().item() / fc.norm().item()      # two identical device runs
-    print(f"f16 parity {cfg}: loss rel {abs(l1 - oloss.item()) / abs(oloss.item()):.2e}, whole gradient {whole:.3e} (device rerun {whole_noise:.3e}), cosine {cos:.6f}")
-    assert whole <= 1e-2 + 3.0 * whole_noise and cos >= 0.9995, (whole, whole_noise, cos)
+    rerun = (fa - fc).norm().item() / fc.norm().item()
+    print(f"f16 parity {cfg}: loss rel {loss_rel:.2e}, whole gradient {whole:.3e} (identical device rerun {rerun:.3e}), cosine {cos:.6f}; "
+          f"assignment pinned: {n_fg} foreground anchors, {flips} would flip under the oracle's own 16-bit logits")
+    assert loss_rel <= 2e-3, (l1, oloss.item())
+    assert whole <= 1e-2 and cos >= 0.9995, (whole, cos)
     gmax = max(og[k].norm().item() for k in keys)
-    rel, rel_noise, dist, noise_abs = [], [], {}, {}
+    rel, bad = [], []
     for k in keys:
-        dist[k] = (g1[k] - og[k]).norm().item()
-        noise_abs[k] = max((g1[k] - g2[k]).norm().item(), (g1[k] - g3[k]).norm().item(), (g2[k] - g3[k]).norm().item())
-        rel.append(dist[k] / (og[k].norm().item() + 1e-4 * gmax))
-        rel_noise.append(noise_abs[k] / (og[k].norm().item() + 1e-4 * gmax))
-    # a tensor's own three-run spread is a 3-sample estimate (it can be small by chance on one of ~300 tensors): never take
-    # the noise scale below the 90th percentile of the relative spreads of all tensors
-    q90 = float(np.quantile(rel_noise, 0.9))
-    bad = [(k, dist[k], og[k].norm().item(), noise_abs[k]) for k in keys
-           if dist[k] > 0.02 * og[k].norm().item() + 3.0 * max(noise_abs[k], q90 * og[k].norm().item()) + 1e-4 * gmax]
-    assert not bad, (q90, bad[:8])
-    # how chaotic the trained state is varies from run to run (the pre-training itself uses f32 atomics): every bar is
-    # "2e-3 / 1e-2 / 2 % beyond what two identical device runs differ by"
-    assert float(np.median(rel)) <= 1e-2 + 3.0 * float(np.median(rel_noise)), (float(np.median(rel)), float(np.median(rel_noise)))
-    return {"loss_rel": abs(l1 - oloss.item()) / abs(oloss.item()), "whole": whole, "cos": cos, "median": float(np.median(rel)), "max": max(rel)}
+        d = (g1[k] - og[k]).norm().item()
+        rel.append(d / (og[k].norm().item() + 1e-4 * gmax))
+        if d > 0.02 * og[k].norm().item() + 1e-4 * gmax:
+            bad.append((k, d, og[k].norm().item()))
+    assert not bad, bad[:8]
+    assert float(np.median(rel)) <= 1e-2, float(np.median(rel))
+    return {"loss_rel": loss_rel, "whole": whole, "cos": cos, "median": float(np.median(rel)), "max": max(rel), "flips": flips, "rerun": rerun}

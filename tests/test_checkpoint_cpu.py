@@ -83,3 +83,42 @@ def test_sy11_checkpoint_round_trip():
     for k, v in ckpt["sy11_state_dict"].items():
         assert v.dtype in (torch.float16, torch.int64, torch.float32)
     assert ckpt["sy11_yaml"]["nc"] == 3
+
+
+def test_reference_pickle_carrying_a_criterion_loads_and_saves_again():
+    """A reference model pickled after its first loss call carries `criterion` (v8DetectionLoss with BboxLoss / DFLoss /
+    TaskAlignedAssigner children, nn/tasks.py:288-300).  Its state is the reference's, not this build's: the loader drops it
+    (BaseModel.loss rebuilds it) and the loaded model pickles again."""
+    import types
+
+    from sy11.engine.checkpoint import attempt_load_one_weight, save_checkpoint
+    from sy11.nn.tasks import DetectionModel
+    fake = {}
+    for modname, names in (("ultralytics.utils.loss", ("v8DetectionLoss", "BboxLoss", "DFLoss")), ("ultralytics.utils.tal", ("TaskAlignedAssigner",))):
+        mod = types.ModuleType(modname)
+        for n in names:
+            setattr(mod, n, type(n, (object,) if n == "v8DetectionLoss" else (torch.nn.Module,), {"__module__": modname}))
+        fake[modname] = mod
+    for pkg in ("ultralytics", "ultralytics.utils"):                 # parent packages, so that pickle's import of the leaf resolves
+        fake[pkg] = types.ModuleType(pkg)
+        fake[pkg].__path__ = []
+    sys.modules.update(fake)
+    try:
+        L, T = fake["ultralytics.utils.loss"], fake["ultralytics.utils.tal"]
+        m = DetectionModel("yolo11n.yaml", nc=3, verbose=False)
+        crit = L.v8DetectionLoss()
+        bbox = L.BboxLoss()
+        bbox.dfl_loss = L.DFLoss()
+        crit.__dict__.update(bce=torch.nn.BCEWithLogitsLoss(reduction="none"), stride=torch.tensor([8.0, 16.0, 32.0]), nc=3, no=67, reg_max=16,
+                             use_dfl=True, assigner=T.TaskAlignedAssigner(), bbox_loss=bbox, proj=torch.arange(16.0))
+        m.criterion = crit
+        buf = io.BytesIO()
+        torch.save({"epoch": 0, "ema": None, "model": m, "train_args": {"box": 7.5, "cls": 0.5, "dfl": 1.5}}, buf)
+    finally:
+        for k in fake:
+            sys.modules.pop(k, None)
+    model, ckpt = attempt_load_one_weight(io.BytesIO(buf.getvalue()))
+    assert "ultralytics.utils.loss" not in sys.modules
+    assert getattr(model, "criterion", None) is None                 # dropped: first training loss call builds sy11's own
+    out = io.BytesIO()
+    assert save_checkpoint(out, ema_model=model, updates=1) > 1000    # and the model pickles again (module-level holder classes)

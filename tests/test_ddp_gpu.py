@@ -1,7 +1,8 @@
 """GPU: the data-parallel path with REAL kernels — two ranks share cuda:0 over the gloo backend (one-GPU box; RCCL needs one
 GPU per rank).  Each rank runs DetectionTrainer with hipGraph replay: the backward is captured as TWO graphs around the bucket
-mark, the first bucket's all-reduce is issued between them, rank 0's tuner picks reach rank 1, and both ranks hold bit-identical
-weights after 6 steps although they saw different batches."""
+mark (SY11_DDP_OVERLAP=1; the default is one graph and ONE all-reduce after it), the first bucket's all-reduce is issued between
+them, rank 0's tuner picks reach rank 1, and both ranks hold bit-identical weights after 6 steps although they saw different
+batches.  The RCCL flavour of this test (one GPU per rank) is tests/test_ddp_nccl_gpu.py; it skips on a one-GPU box."""
 import os
 import sys
 import textwrap
@@ -36,7 +37,8 @@ SCRIPT = textwrap.dedent("""
     entries = tr.model.__dict__["_sy11_graph_cfg"]["entries"]
     assert len(entries) == 1
     e = next(iter(entries.values()))
-    assert e.g_bwd2 is not None                                  # the backward was captured in two parts around the bucket mark
+    # SY11_DDP_OVERLAP=1: the backward was captured in two parts around the bucket mark; default: one graph, one all-reduce after it
+    assert (e.g_bwd2 is not None) == (os.environ.get("SY11_DDP_OVERLAP", "0") == "1")
     mine = tr.flat.flat.clone()
     theirs = mine.clone(); dist.broadcast(theirs, 0)
     assert torch.equal(mine, theirs), (mine - theirs).abs().max()
@@ -49,10 +51,11 @@ SCRIPT = textwrap.dedent("""
 """)
 
 
-def test_two_ranks_bucketed_backward_identical_weights(tmp_path):
+@pytest.mark.parametrize("overlap", ["0", "1"], ids=["one_allreduce_default", "two_bucket_overlap"])
+def test_two_ranks_identical_weights(tmp_path, overlap):
     script = tmp_path / "ddp_gpu.py"
     script.write_text(SCRIPT.format(root=str(ROOT)))
     sys.path.insert(0, str(ROOT / "spectrogram-yolov11_amd"))
     from sy11.engine import ddp
-    env = dict(os.environ, OMP_NUM_THREADS="2", SY11_TUNE="1")
+    env = dict(os.environ, OMP_NUM_THREADS="2", SY11_TUNE="1", SY11_DDP_OVERLAP=overlap)
     assert ddp.launch([str(script)], 2, env=env, timeout=600) == [0, 0]

@@ -1,0 +1,65 @@
+"""GPU (needs >= 2 visible GPUs — skips on the one-GPU test box): the data-parallel path over RCCL, one process per GPU, as
+`bench.py --gpus N` and the trainer run it.  Both flavours of the gradient exchange: the default (ONE all-reduce of the flat
+gradient buffer after the backward graph) and SY11_DDP_OVERLAP=1 (two-bucket exchange: the first bucket is reduced on RCCL's
+stream beside the second backward graph).  After 6 steps on different batches the ranks must hold bit-identical weights, and the
+overlapped flavour must reproduce the default one bit for bit (the same sums in the same order, only scheduled differently)."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+SCRIPT = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(r"{root}", "spectrogram-yolov11_amd")); sys.path.insert(0, r"{root}")
+from sy11 import _lib
+from sy11.engine import ddp
+from sy11.engine.trainer import DetectionTrainer
+from sy11.nn.tasks import DetectionModel
+rank, local, world = ddp.setup_process_group("nccl")
+dev = torch.device("cuda", local)
+torch.manual_seed(5 + rank)
+m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
+tr = DetectionTrainer(m, batch_size=8, device=dev, overrides={{"amp": True, "nbs": 8 * world, "warmup_epochs": 0}}, world_size=world, graphs=True)
+losses = []
+for i in range(6):
+    g = torch.Generator().manual_seed(100 * rank + i)
+    b = {{"img": torch.rand(8, 3, 256, 256, generator=g).to(dev), "batch_idx": torch.arange(8.0).to(dev),
+         "cls": torch.randint(0, 80, (8, 1), generator=g).float().to(dev), "bboxes": (0.3 + 0.3 * torch.rand(8, 4, generator=g)).to(dev)}}
+    losses.append(float(tr.train_step(b)[0]))
+torch.cuda.synchronize()
+e = next(iter(tr.model.__dict__["_sy11_graph_cfg"]["entries"].values()))
+assert (e.g_bwd2 is not None) == (os.environ.get("SY11_DDP_OVERLAP", "0") == "1")
+mine = tr.flat.flat.clone()
+theirs = mine.clone(); dist.broadcast(theirs, 0)
+assert torch.equal(mine, theirs), float((mine - theirs).abs().max())
+picks = _lib.tune_export()
+box = [picks]; dist.broadcast_object_list(box, 0)
+assert sorted(picks[i:i + 16] for i in range(0, len(picks), 16)) == sorted(box[0][i:i + 16] for i in range(0, len(box[0]), 16))
+if rank == 0:
+    torch.save({{"flat": mine.cpu(), "losses": losses}}, r"{out}")
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: fewer than 2 GPUs visible")
+def test_two_ranks_over_rccl_identical_weights_both_exchange_flavours(tmp_path):
+    sys.path.insert(0, str(ROOT / "spectrogram-yolov11_amd"))
+    from sy11.engine import ddp
+    outs = []
+    for overlap in ("0", "1"):
+        out = tmp_path / f"w{overlap}.pt"
+        script = tmp_path / f"ddp_nccl_{overlap}.py"
+        script.write_text(SCRIPT.format(root=str(ROOT), out=str(out)))
+        # rank 0 measures tile configurations in the first flavour; the second replays those picks so that both run the same kernels
+        env = dict(os.environ, OMP_NUM_THREADS="2", SY11_DDP_OVERLAP=overlap, SY11_TUNE="0")
+        assert ddp.launch([str(script)], 2, env=env, timeout=900) == [0, 0]
+        outs.append(torch.load(out))
+    # f32 atomics reorder sums run to run: the two flavours agree to rounding, not bit for bit
+    a, b = outs[0]["flat"], outs[1]["flat"]
+    assert (a - b).norm().item() <= 2e-3 * a.norm().item()
+    assert all(abs(x - y) <= 2e-2 * abs(x) for x, y in zip(outs[0]["losses"], outs[1]["losses"]))

@@ -447,7 +447,7 @@ def test_ddp_real_trainer_step_accumulate_buckets_and_early_stop_gloo_world2(tmp
     script.write_text(DDP_TRAINER_SCRIPT.format(root=str(ROOT)))
     sys.path.insert(0, str(ROOT / "spectrogram-yolov11_amd"))
     from sy11.engine import ddp
-    codes = ddp.launch([str(script)], 2, env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=300)
+    codes = ddp.launch([str(script)], 2, env=dict(os.environ, OMP_NUM_THREADS="1", SY11_DDP_OVERLAP="1"), timeout=300)
     assert codes == [0, 0]
 
 
@@ -461,6 +461,7 @@ def test_train_device_list_spawns_one_child_per_gpu(monkeypatch, tmp_path):
 
     def fake_launch(args, nproc, env=None, timeout=None):
         seen.update(args=list(args), nproc=nproc, env=env, src=open(args[0]).read())
+        (tmp_path / "results.json").write_text('[{"epoch": 0, "metrics": {"fitness": 0.5}}]')     # what rank 0 of the children leaves behind
         return [0] * nproc
     monkeypatch.setattr(ddp, "launch", fake_launch)
     monkeypatch.delenv("RANK", raising=False)
@@ -469,4 +470,11 @@ def test_train_device_list_spawns_one_child_per_gpu(monkeypatch, tmp_path):
     assert seen["nproc"] == 2 and seen["env"]["HIP_VISIBLE_DEVICES"] == "0,1"
     assert "m.train(**P['kw'])" in seen["src"] and "yolo11n.yaml" in seen["src"] and '\\"lr0\\": 0.02' in seen["src"] and '\\"epochs\\": 2' in seen["src"]
     assert not os.path.exists(seen["args"][0])                    # the temporary launcher file is removed
-    assert str(out).startswith(str(tmp_path))
+    assert out == [{"epoch": 0, "metrics": {"fitness": 0.5}}] and y.metrics == {"fitness": 0.5}      # same return type as one process: the history
+    from pathlib import Path
+    y.train(data={"train": "x", "names": {0: "a"}, "nc": 1}, epochs=1, device=[0, 1], save_dir=Path(tmp_path), resume=Path("last.pt"))   # Path-valued arguments serialise
+    import pytest as _pt
+    from sy11._lib import Sy11Error
+    with _pt.raises(Sy11Error):
+        _device_list("mps")
+    assert _device_list("cuda") == [0]
