@@ -38,7 +38,7 @@ TRAIN_GFLOP_PER_IMG = 64.40         # fwd + dgrad + wgrad (first layer has no dg
 FUSION_FWD_GFLOP_PER_IMG = 18.892   # yolo11s_fusion_sand3_new, nc = 2
 PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0               # HBM3E spec peak (~6300 achievable), MI355X_MICROARCH.md
-PROFILE_DIR = ROOT / "profiles" / "r02"
+PROFILE_DIR = ROOT / "profiles" / "r03"
 
 # kernel family -> the C-ABI entry points that launch it, and the kernel symbols a rocprofv3 trace shows for it
 FAMILIES = {
@@ -105,7 +105,7 @@ def host_cpus():
     return n
 
 
-def cpu_baseline(batch=8, imgsz=640, leg_budget_s=22.0):
+def cpu_baseline(batch=8, imgsz=640, leg_budget_s=12.0, full_batch=64):
     """SURVEY §8(d) / BASELINE.md §3: the oracle (plain PyTorch fp32 restatement of the reference path) on this host's cores, at
     n = 7 threads (the reference's own default min(8, ncpu - 1), utils/__init__.py:44) and n = all usable cores; warm-up + up to 5
     timed iterations each of (a) eval forward and (b) train fwd + loss + bwd, every leg bounded to ~20 s (>= 2 timed iterations).
@@ -142,7 +142,7 @@ def cpu_baseline(batch=8, imgsz=640, leg_budget_s=22.0):
         def fwd():
             with torch.no_grad():
                 R.forward(esd, layers, img, train=False)
-        dt, it = timed(fwd, 1, 5, f"eval forward, {n} threads")
+        dt, it = timed(fwd, 1, 3, f"eval forward, {n} threads")
         runs.append({"mode": "eval forward", "threads": n, "batch": batch, "iters": it, "img_s": round(batch / dt, 3),
                      "gflops": round(batch / dt * FWD_GFLOP_PER_IMG, 1)})
         tsd = {k: v.clone() for k, v in sd.items()}
@@ -156,12 +156,39 @@ def cpu_baseline(batch=8, imgsz=640, leg_budget_s=22.0):
             loss.backward()
             for v in tsd.values():
                 v.grad = None
-        dt, it = timed(train, 1, 5, f"train fwd+loss+bwd, {n} threads")
+        dt, it = timed(train, 1, 3, f"train fwd+loss+bwd, {n} threads")
         runs.append({"mode": "train fwd+loss+bwd", "threads": n, "batch": batch, "iters": it, "img_s": round(batch / dt, 3),
                      "gflops": round(batch / dt * TRAIN_GFLOP_PER_IMG, 1)})
-    best = max((r for r in runs if r["mode"].startswith("train")), key=lambda r: r["img_s"])
+    # ... and the workload's own batch (64) once on all cores: 1 warm-up + 2 timed train iterations (~25 s of CPU work, ~35 GB of
+    # saved activations); falls back to the batch-8 figure when the host cannot hold it
+    full = None
+    if full_batch and full_batch != batch:
+        try:
+            torch.set_num_threads(ncpu)
+            img64 = torch.rand(full_batch, 3, imgsz, imgsz)
+            lab64 = synthetic_labels(full_batch, 0, "cpu")
+            tsd = {k: v.clone() for k, v in sd.items()}
+            for k, v in tsd.items():
+                if v.dtype.is_floating_point and "running" not in k:
+                    v.requires_grad_(True)
+
+            def train64():
+                maps = R.forward(tsd, layers, img64, train=True)
+                loss, _ = loss_ref.detection_loss(maps, lab64, nc=80)
+                loss.backward()
+                for v in tsd.values():
+                    v.grad = None
+            dt, it = timed(train64, 1, 2, f"train fwd+loss+bwd at batch {full_batch}, {ncpu} threads")
+            full = {"mode": "train fwd+loss+bwd", "threads": ncpu, "batch": full_batch, "iters": it, "img_s": round(full_batch / dt, 3),
+                    "gflops": round(full_batch / dt * TRAIN_GFLOP_PER_IMG, 1)}
+            runs.append(full)
+            del img64, tsd
+        except (MemoryError, RuntimeError) as e:
+            print(f"[bench] cpu baseline at batch {full_batch} not possible on this host: {e!r}", file=sys.stderr, flush=True)
+    best = full or max((r for r in runs if r["mode"].startswith("train")), key=lambda r: r["img_s"])
+    frac = "the bench workload's own batch" if best["batch"] == full_batch else f"the bench workload at 1/{max(full_batch // best['batch'], 1)} of its batch"
     return {"value": best["img_s"], "unit": "spectrogram-images/s", "cores": best["threads"], "kind": "port",
-            "sample": f"yolo11s {imgsz}x{imgsz} at batch {batch} (the bench workload at 1/8 of its batch): train fwd+loss+bwd, "
+            "sample": f"yolo11s {imgsz}x{imgsz} at batch {best['batch']} ({frac}): train fwd+loss+bwd, "
                       f"{best['iters']} timed + 1 warm-up iterations, oracle/yolo11_ref.py + loss_ref.py, fp32, {best['threads']} torch threads",
             "host_cpus": ncpu, "runs": runs, "wall_s": round(time.perf_counter() - t_start, 1)}
 
@@ -194,6 +221,62 @@ def measured_peaks(dev):
     return {"mfma_f16_tflops": round(tf, 1), "mfma_f16_vs_datasheet": round(tf / PEAK_TFLOPS["f16"], 3),
             "device_copy_GBps": round(gbs, 1), "device_copy_vs_datasheet": round(gbs / PEAK_HBM_GBS, 3),
             "how": "sy11_peak_mfma_f16 (2048 workgroups x 4 waves x 32000 v_mfma_f32_32x32x16_f16, registers only); torch copy_ of 1 GiB (read + write bytes)"}
+
+
+def predict_val_leg(model, img, batch, nc, steps):
+    """The predict / validation side at the bench's batch (BASELINE configs[0] scaled up; models/yolo/detect/val.py:93-106):
+    fused eval forward -> Detect decode -> non_max_suppression(conf 0.001, iou 0.7, multi_label, max_det 300) on the HIP NMS.
+    A random-init head scores every class ~1e-5 (Detect.bias_init), i.e. nothing would pass conf 0.001: the NMS is therefore fed
+    SYNTHETIC decoded predictions with a stated candidate density (1 % of the anchor x class pairs above the threshold: 6 720
+    candidates per image, a mid-training validation batch) next to the model's own decode timing."""
+    from sy11 import _lib, ops as K
+    from sy11.utils.ops import non_max_suppression
+    dev = img.device
+    with torch.no_grad():
+        y, maps = model(img)
+    nhwc = [m.permute(0, 2, 3, 1).contiguous() for m in maps]
+    strides = [float(v) for v in model.stride]
+    ev = lambda: torch.cuda.Event(enable_timing=True)          # noqa: E731
+    K.detect_decode(nhwc, strides, nc)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(10):
+        K.detect_decode(nhwc, strides, nc)
+    e1.record()
+    torch.cuda.synchronize()
+    dec_ms = e0.elapsed_time(e1) / 10
+    dec_bytes = sum(m.numel() * 4 for m in nhwc) + y.numel() * 4
+    g = torch.Generator(device=dev).manual_seed(7)
+    A = y.shape[2]
+    pred = torch.empty((batch, 4 + nc, A), device=dev)
+    pred[:, 0:2] = 20 + 600 * torch.rand(batch, 2, A, generator=g, device=dev)
+    pred[:, 2:4] = 8 + 120 * torch.rand(batch, 2, A, generator=g, device=dev) ** 2
+    u = torch.rand(batch, nc, A, generator=g, device=dev)
+    pred[:, 4:] = torch.where(u > 0.99, 0.001 + 0.9 * torch.rand(batch, nc, A, generator=g, device=dev) ** 3, 1e-4 * u)
+    kw = dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300, nc=nc)
+    out = non_max_suppression(pred.clone(), **kw)
+    torch.cuda.synchronize()
+    n_rep = max(min(steps // 4, 5), 2)
+    _lib.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(n_rep):
+        out = non_max_suppression(pred.clone(), **kw)
+    torch.cuda.synchronize()
+    nms_ms = (time.perf_counter() - t0) / n_rep * 1e3
+    prof, _lib.PROFILE = _lib.PROFILE, None
+    k_ms = sum(e0.elapsed_time(e1) for name, e0, e1, _ in prof if name == "sy11_nms_sorted") / n_rep
+    cand = int((pred[:, 4:] > 0.001).sum().item()) / batch
+    pairs = batch * cand * cand / 2                             # IoU evaluations of the bit-matrix kernel (upper triangle)
+    return {"workload": "predict / val side at bs 64: Detect decode (model output) + non_max_suppression(conf 0.001, iou 0.7, multi_label, max_det 300) "
+                        "on synthetic decoded predictions, 1 % of anchor x class pairs above conf",
+            "candidates_per_image": round(cand, 1), "kept_per_image": round(sum(len(o) for o in out) / batch, 1),
+            "detect_decode": {"kernel": "detect_decode_kernel", "ms": round(dec_ms, 4), "algorithmic_bytes": dec_bytes, "bound": "hbm",
+                              "achieved": round(dec_bytes / dec_ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": round(dec_bytes / dec_ms / 1e6 / PEAK_HBM_GBS, 4)},
+            "nms": {"kernel": "nms_mask_kernel + nms_sweep_kernel", "wrapper_ms_per_batch": round(nms_ms, 3), "kernel_ms_per_batch": round(k_ms, 3),
+                    "images_per_s": round(batch / (nms_ms * 1e-3), 1), "iou_pairs_per_batch": int(pairs),
+                    "giga_pairs_per_s": round(pairs / max(k_ms, 1e-9) / 1e6, 2),
+                    "note": "latency / VALU bound (one 64-bit mask word per 64 IoU tests, then a single-wave greedy sweep per image); bit-exact kept set"}}
 
 
 def family_of(name, meta):
@@ -287,6 +370,24 @@ def main():
         dt = tmax.item()
     ms = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
+    exposed = None
+    if world > 1:
+        # the gradient exchange as the launch stream sees it: events around the hook's collective(s) (the stream-side wait for RCCL
+        # included) over 5 more steps — what of the all-reduce is NOT hidden behind compute
+        from sy11.engine import module_post_backward
+        hk = module_post_backward.get(id(tr.model.__dict__.get("_sy11_grads")))
+        if hk is not None:
+            hk.timing = []
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            spans = [e0.elapsed_time(e1) for e0, e1 in hk.timing]
+            hk.timing = None
+            per_step = sum(spans) / 5 if spans else 0.0
+            t_all = torch.tensor([per_step], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+            exposed = {"allreduce_ms_per_step_on_launch_stream": round(t_all.item(), 3), "bytes": int(tr.grad_store.flat.numel() * 4),
+                       "overlap": bool(ddp.OVERLAP), "how": "HIP events on the launch stream around the collective calls of the gradient hook, max over ranks"}
     fwd_gflop = FUSION_FWD_GFLOP_PER_IMG if "fusion" in a.model else FWD_GFLOP_PER_IMG
     train_gflop = 3 * fwd_gflop - 0.177 if "fusion" in a.model else TRAIN_GFLOP_PER_IMG
 
@@ -380,8 +481,18 @@ def main():
                 traffic = {"bytes_per_step": round(ft["GB_per_step"] * 1e9), "kernel_launches_per_step": ft["launches_per_step"],
                            "bytes_per_kernel_launch": round(ft["GB_per_step"] * 1e9 / max(ft["launches_per_step"], 1)),
                            "vs_algorithmic": round(ft["GB_per_step"] * 1e9 / max(f["bytes"], 1.0), 3),
-                           "source": "profiles/r02/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections)"}
-        roof = {"kernel": name, "kernel_symbols": list(FAMILIES.get(name, {}).get("symbols", ())),
+                           "source": f"profiles/{PROFILE_DIR.name}/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections)",
+                           "commit": json.loads(tj.read_text()).get("commit"), "commands": json.loads(tj.read_text()).get("commands")}
+        dominant = None
+        kcsv = PROFILE_DIR / "z_final_per_step_kernels.csv"
+        if kcsv.exists():                                        # hottest kernel SYMBOL of the family in the committed graph-replay trace
+            import csv
+            rows = [r for r in csv.DictReader(open(kcsv)) if r["family"] == name]
+            if rows:
+                top = max(rows, key=lambda r: float(r["ms_per_step"]))
+                dominant = {"symbol": top["kernel"], "launches_per_step": float(top["launches_per_step"]), "ms_per_step": float(top["ms_per_step"]),
+                            "avg_us_per_launch": float(top["avg_us_per_launch"]), "source": f"profiles/{PROFILE_DIR.name}/z_final_per_step_kernels.csv (rocprofv3 --kernel-trace --stats of this command)"}
+        roof = {"kernel": name, "kernel_symbols": list(FAMILIES.get(name, {}).get("symbols", ())), "dominant_symbol": dominant,
                 "bound": "hbm" if hbm_bound else "mfma",
                 "achieved": round(ach_gb, 1) if hbm_bound else round(ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
@@ -424,6 +535,12 @@ def main():
         fwd_only["fused_eval"] = {"workload": "model.fuse() + eval forward incl. Detect decode (predictor path), bs=64", "value": round(a.batch / pdt, 1),
                                   "ms_per_step": round(pdt * 1e3, 3), "conv_tflops": round(a.batch / pdt * fwd_gflop / 1e3, 2),
                                   "conv_roofline_frac": round(a.batch / pdt * fwd_gflop / 1e3 / PEAK_TFLOPS[a.dtype], 4)}
+        try:
+            fwd_only["predict_val"] = predict_val_leg(m, img, a.batch, a.nc, a.steps)
+            pv = fwd_only["predict_val"]
+            pv["val_images_per_s_forward_plus_nms"] = round(a.batch / (pdt + pv["nms"]["wrapper_ms_per_batch"] * 1e-3), 1)
+        except Exception as e:                                   # a reporting leg must never take the headline down
+            fwd_only["predict_val"] = {"error": repr(e)}
 
     extra = None
     if rank == 0 and world == 1 and a.mode == "train" and not a.no_extras and a.model == "yolo11s.yaml":
@@ -463,7 +580,7 @@ def main():
                        "parallelism": f"dp{world}", "weights": "random-init", "nc": a.nc},
             "conv_tflops": round(value * gflop / 1e3, 2),
             "conv_roofline_frac": round(value * gflop / 1e3 / PEAK_TFLOPS[a.dtype], 4),
-            "roofline": roof, "peaks": peaks, "cpu_baseline": cpu, "forward_only": fwd_only, "extra": extra,
+            "roofline": roof, "peaks": peaks, "cpu_baseline": cpu, "forward_only": fwd_only, "extra": extra, "gradient_exchange": exposed,
         }
         print(json.dumps(out))
     if world > 1:

@@ -211,6 +211,12 @@ int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
 int sy11_maxpool5_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* dy, int32_t dy_ld,
                       const uint8_t* idx, void* dx, int32_t dx_ld, int32_t accumulate, void* stream);
 /* flat dtype cast (f32 <-> f16 / bf16), n elements                                                          */
+/* backward of a bias conv with f32 output (Detect's last 1x1 convs, nn/modules/head.py:44-55; autograd of nn.Conv2d bias +
+ * autocast's cast of the incoming gradient): dz f32 (M x N, pixel stride dz_ld) -> dy (dtype, M x npad contiguous, channels >= N
+ * zero) and dbias[c] += sum_m dz[m][c] (dbias may be NULL).  partials != NULL ([partial_rows][N] scratch): ordered reduction —
+ * one partial row per workgroup, folded in row order by a second launch (bit-reproducible).                             */
+int sy11_bias_grad_cast(int32_t dtype, int64_t M, int32_t N, int32_t npad, const float* dz, int32_t dz_ld, void* dy, float* dbias,
+                        float* partials, int32_t partial_rows, void* stream);
 int sy11_cast(int32_t src_dtype, int32_t dst_dtype, int64_t n, const void* src, void* dst, void* stream);
 
 /* ---- C2PSA attention core: softmax(q^T k * scale) applied to v (nn/modules/block.py:1925-1931) ---------- */
@@ -247,12 +253,53 @@ int sy11_det_loss_assign(int32_t B, int32_t nc, int32_t nl, const float* const* 
 int sy11_det_loss_terms(int32_t B, int32_t nc, int32_t nl, const float* const* maps, const int32_t* hs, const int32_t* ws,
                         const float* strides, int32_t G, const float* gt, const int32_t* assign, const float* norm,
                         float* sums, void* stream);
-/* dmaps[l] = d(B * (gb*box + gc*cls + gd*dfl) / tss) / d maps[l], scaled by the DEVICE scalar *upstream_over_tss
- * (= upstream gradient / max(tss, 1)); no host synchronisation.                                                    */
+/* dmaps[l] = d(B * (gb*box + gc*cls + gd*dfl) / tss) / d maps[l], scaled by the DEVICE scalar *upstream and, when given, by the
+ * second device scalar *inv_tss (out[4] of sy11_det_loss_finish); with inv_tss = NULL `upstream` must already carry
+ * 1 / max(tss, 1).  No host synchronisation.                                                                       */
 int sy11_det_loss_bwd(int32_t B, int32_t nc, int32_t nl, const float* const* maps, float* const* dmaps, const int32_t* hs,
                       const int32_t* ws, const float* strides, int32_t G, const float* gt, const int32_t* assign,
-                      const float* norm, const float* upstream_over_tss, float gain_box, float gain_cls, float gain_dfl,
-                      void* stream);
+                      const float* norm, const float* upstream, const float* inv_tss, float gain_box, float gain_cls,
+                      float gain_dfl, void* stream);
+/* v8DetectionLoss.preprocess (utils/loss.py:194-207): n targets given as three strided f32 columns (image index, class, xywh
+ * normalised; strides in elements) -> gt (B, G, 5) [cls, x1, y1, x2, y2] in pixels (scale_w / scale_h = image width / height),
+ * an image's targets in their original order, the rest of its G rows zero.  G = the largest target count of one image.  */
+int sy11_det_loss_pack_targets(int32_t n, int32_t B, int32_t G, const float* batch_idx, int32_t idx_stride, const float* cls,
+                               int32_t cls_stride, const float* bboxes, int32_t box_stride, float scale_w, float scale_h, float* gt,
+                               void* stream);
+/* loss.py:268-275: out[0] = batch_size * sum_i gain_i * term_i / max(tss, 1), out[1..3] = the gained items, out[4] = 1 / max(tss, 1);
+ * the 64 slots of `sums` are folded in index order.                                                                  */
+int sy11_det_loss_finish(const float* sums, int32_t B, float gain_box, float gain_cls, float gain_dfl, float* out, void* stream);
+
+/* ---- trainer step over flat buffers (engine/trainer.py:585-593 optimizer_step: GradScaler.unscale_ -> clip_grad_norm_(10.0) ->
+ *      optimizer.step -> GradScaler.update -> zero_grad -> ModelEMA.update, utils/torch_utils.py:495-531; the optimizers are
+ *      torch.optim.SGD(nesterov=True) / AdamW as built by build_optimizer, trainer.py:758-819).  Two launches:
+ *      sy11_opt_grad_norm writes `nparts` ordered partial sums of (grad / scale)^2 plus snapshots of 1/scale and of the Adam
+ *      step counter into ws (sy11_opt_workspace_floats(nparts) floats); sy11_opt_step folds them in a fixed order (bit-
+ *      reproducible clip factor), applies the update to param / mom (/ sq), averages the UPDATED parameters and the float
+ *      buffers into the EMA, zeroes grad, and updates the loss scale like GradScaler.update.  A non-finite norm with amp = 1
+ *      skips the parameter update (GradScaler.step) but not the EMA.  Flat buffers: three consecutive groups ending at
+ *      group_end[0..2] (multiples of 4), all 16-byte aligned.                                                            */
+typedef struct sy11_opt_desc {
+  int64_t n;                   /* elements of param / grad / mom / sq / ema                                      */
+  int64_t n_buf;               /* elements of buf / ema_buf (BatchNorm running statistics), may be 0             */
+  int64_t group_end[3];        /* end of each parameter group inside the flat buffers                            */
+  float lr[3], momentum[3], weight_decay[3];    /* AdamW: momentum = beta1                                      */
+  int32_t kind;                /* 0 SGD nesterov (dampening 0), 1 AdamW                                          */
+  float beta2, eps;            /* AdamW                                                                          */
+  float max_norm;              /* clip_grad_norm_ threshold (10.0)                                               */
+  float ema_decay;             /* d of this update: ema = d * ema + (1 - d) * value                              */
+  int32_t amp;                 /* 1: gradients carry the loss scale; overflow skips the update                   */
+  float growth_factor, backoff_factor; int32_t growth_interval;      /* GradScaler: 2.0, 0.5, 2000              */
+  int32_t nparts;              /* partial sums written by sy11_opt_grad_norm (<= 4096)                           */
+} sy11_opt_desc;
+int sy11_opt_workspace_floats(int32_t nparts);
+int sy11_opt_grad_norm(int64_t n, const float* grad, const float* scale, const float* adam_step, float* ws, int32_t nparts,
+                       void* stream);
+/* scale / growth_tracker: GradScaler's device scalars (updated in place; NULL with amp = 0); adam_step: device f32 count of
+ * applied AdamW steps (updated in place; NULL for SGD); norm_out: optional [2] = {total gradient norm, update skipped}.  */
+int sy11_opt_step(const sy11_opt_desc* d, float* param, float* grad, float* mom, float* sq, float* ema, const float* buf,
+                  float* ema_buf, const float* ws, float* scale, int32_t* growth_tracker, float* adam_step, float* norm_out,
+                  void* stream);
 
 /* ---- IQ -> STFT -> power -> mel -> log producer (no reference code: README.md:7; spec in DESIGN.md) ------ */
 /* iq: (B, L) interleaved complex64; db: (B, n_frames, n_mel) f32 dB (frame-major: coalesced stores);

@@ -17,6 +17,7 @@
 // Waves are specialised for the copies only (every wave does MFMAs): waves 0-1 issue the filter stages, waves 2-3 the patch of the
 // NEXT slab in six slices during taps 0..5 — vmcnt counts per wave, so each role waits for its own copies with a trivial count and the
 // stage barrier publishes them.
+#include "det.h"
 #include "igemm_args.h"
 #include <type_traits>
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void h
   static_assert(WM * WN == 4 && MI >= 1 && NI >= 1 && NVALID <= BM, "tile layout");
   static_assert(BM * BN * 2 <= 2 * A_BYTES + NSTB * B_BYTES, "epilogue staging must fit the dead operand buffers");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + NSTB * B_BYTES];
-  __shared__ float s_red[2 * BN];
+  __shared__ float s_red[WM * 2 * BN];           // [wave row wm][sum | sumsq][channel]: ordered fold, no LDS atomics
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -79,7 +80,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void h
   const int oy0 = tile_y * TH, ox0 = tile_x * TW, bn0 = tile_n * BN;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
 
-  for (int i = tid; i < 2 * BN; i += 256) s_red[i] = 0.f;
 
   // per-tap constants (wave-uniform): row offset inside the patch image, byte offset of the tap's filter columns
   int toff[9], wtap[9];
@@ -280,15 +280,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void h
       const float s2 = ssq[j] + __shfl_xor(ssq[j], 32);
       if (fh == 0) {
         const int col = wn * (BN / WN) + j * 32 + frow;
-        atomicAdd(&s_red[col], s1);
-        atomicAdd(&s_red[BN + col], s2);
+        s_red[wm * 2 * BN + col] = s1;            // one row per wave row: the fold below adds them in index order (bit-reproducible)
+        s_red[wm * 2 * BN + BN + col] = s2;
       }
     }
     __syncthreads();
     if (tid < BN && bn0 + tid < a.N) {
       const long so = (long)(blockIdx.x % a.stat_slots) * a.stat_stride;
-      atomicAdd(a.stat_sum + so + bn0 + tid, s_red[tid]);
-      atomicAdd(a.stat_sq + so + bn0 + tid, s_red[BN + tid]);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < WM; ++r) { t1 += s_red[r * 2 * BN + tid]; t2 += s_red[r * 2 * BN + BN + tid]; }
+      atomicAdd(a.stat_sum + so + bn0 + tid, t1);
+      atomicAdd(a.stat_sq + so + bn0 + tid, t2);
     }
   }
 }
@@ -371,9 +374,19 @@ int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn_code, hipStream_t st) {
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "halo3x3: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg);
   const int epi = halo_epi(a);
+  DetPartials dp;                                   // ordered mode (det.h): one partial statistics row per workgroup
+  const bool det = a.stat_sum && sy11_det(1);
+  if (det) {
+    if (!dp.acquire(st, 2, nwg, a.N)) SY11_FAIL(SY11_ELAUNCH, "halo3x3: ordered-reduction workspace unavailable (%ld x %d floats)", nwg, a.N);
+    a.stat_sum = dp.buf(0); a.stat_sq = dp.buf(1); a.stat_slots = (int)nwg; a.stat_stride = a.N;
+  }
   if (a.sy == 1) halo_launch_tile<1>(a, bn, epi, th, tw, grid, st, tx, ty);
   else halo_launch_tile<2>(a, bn, epi, th, tw, grid, st, tx, ty);
   SY11_LAUNCH_CHECK("halo3x3");
+  if (det) {
+    const int rc = dp.fold(0, a_in.stat_sum);
+    return rc ? rc : dp.fold(1, a_in.stat_sq);
+  }
   return SY11_OK;
 }
 

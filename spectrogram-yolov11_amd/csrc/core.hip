@@ -1,6 +1,7 @@
 // core.hip — version / thread-local error string of libsy11.
 #include "common.h"
 #include "tune.h"
+#include "det.h"
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -18,7 +19,7 @@ extern "C" const char* sy11_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------ run-time options
 static int g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
-static const char* const kOptName[OPT_COUNT] = {"tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder", "igemm_deep", "igemm_bpol", "dgrad_s2_halo", "row_map"};
+static const char* const kOptName[OPT_COUNT] = {"tune", "tune_log", "igemm_cfg", "wgrad_cfg", "igemm_korder", "igemm_deep", "igemm_bpol", "dgrad_s2_halo", "row_map", "deterministic"};
 static void opt_init() {
   auto env = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
   g_opt[OPT_TUNE] = env("SY11_TUNE", 1) != 0;
@@ -30,6 +31,7 @@ static void opt_init() {
   g_opt[OPT_IGEMM_BPOL] = env("SY11_IGEMM_BPOL", 0);
   g_opt[OPT_DGRAD_S2_HALO] = env("SY11_DGRAD_S2_HALO", 1);
   g_opt[OPT_ROW_MAP] = env("SY11_ROW_MAP", 1);
+  g_opt[OPT_DETERMINISTIC] = env("SY11_DETERMINISTIC", 0) != 0;
 }
 int sy11_opt(int which) {
   std::call_once(g_opt_once, opt_init);
@@ -43,7 +45,7 @@ static int opt_index(const char* name) {
 }
 extern "C" int sy11_set_option(const char* name, int32_t value) {
   const int i = opt_index(name);
-  SY11_REQUIRE(i >= 0, "set_option: unknown option '%s' (tune, tune_log, igemm_cfg, wgrad_cfg, igemm_korder, igemm_deep, igemm_bpol, dgrad_s2_halo, row_map)", name ? name : "(null)");
+  SY11_REQUIRE(i >= 0, "set_option: unknown option '%s' (tune, tune_log, igemm_cfg, wgrad_cfg, igemm_korder, igemm_deep, igemm_bpol, dgrad_s2_halo, row_map, deterministic)", name ? name : "(null)");
   std::call_once(g_opt_once, opt_init);
   g_opt[i] = value;
   return SY11_OK;
@@ -52,6 +54,52 @@ extern "C" int sy11_get_option(const char* name, int32_t* value) {
   const int i = opt_index(name);
   SY11_REQUIRE(i >= 0 && value, "get_option: unknown option '%s' or null result pointer", name ? name : "(null)");
   *value = sy11_opt(i);
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ordered-reduction workspace
+// "deterministic" 1 (cfg/default.yaml:29 `deterministic: True`, utils/torch_utils.py:474-492 in the reference): every sum over
+// workgroups is taken in a FIXED order — the reducing kernels write one partial row per workgroup into this workspace and a
+// fold kernel adds the rows in index order (det.h).  One buffer per stream, grown geometrically, old buffers are kept alive (a
+// captured hipGraph may still point into them); sized during the eager warm-up steps, so capture never allocates.
+namespace {
+struct DetWs { void* p = nullptr; size_t bytes = 0; };
+std::mutex g_det_mu;
+std::unordered_map<hipStream_t, DetWs> g_det_ws;
+}  // namespace
+float* sy11_det_workspace(hipStream_t st, size_t bytes) {
+  std::lock_guard<std::mutex> g(g_det_mu);
+  DetWs& w = g_det_ws[st];
+  if (bytes <= w.bytes) return (float*)w.p;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+  if (cs != hipStreamCaptureStatusNone) {
+    // cannot allocate inside a capture.  The engine captures on a fresh stream after eager warm-up steps of the same shapes on the
+    // launch stream, and replays the graph ON that launch stream, in order with its eager kernels: the warm-up's buffer is free
+    // whenever a node of this graph runs.  (Ordered mode therefore excludes the opt-in side / branch streams of the engine.)
+    for (auto& kv : g_det_ws)
+      if (kv.second.bytes >= bytes) return (float*)kv.second.p;
+    return nullptr;                                                    // nothing large enough: the caller reports an error
+  }
+  size_t want = w.bytes ? w.bytes * 2 : (size_t)64 << 20;
+  while (want < bytes) want *= 2;
+  void* q = nullptr;
+  if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  w.p = q; w.bytes = want;                                             // the previous buffer is deliberately not freed (see above)
+  return (float*)q;
+}
+
+__global__ __launch_bounds__(256) void zero_floats_kernel(float4* __restrict__ p, size_t n4) {
+  const float4 z = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = z;
+}
+int sy11_zero_floats(float* p, size_t n, hipStream_t st) {               // p: 16-byte aligned (workspace base + multiples of 4 floats)
+  if (n == 0) return SY11_OK;
+  const size_t n4 = (n + 3) / 4;                                          // the workspace is allocated in 64 MB steps: the tail is ours
+  size_t g = (n4 + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(zero_floats_kernel, dim3((unsigned)g), dim3(256), 0, st, (float4*)p, n4);
+  SY11_LAUNCH_CHECK("zero_floats");
   return SY11_OK;
 }
 

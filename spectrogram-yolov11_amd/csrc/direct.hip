@@ -2,6 +2,7 @@
 // 3-channel stem.  Both are HBM/L2-bound (depthwise: 4.5 FLOP/B; stem: K = 27), so no MFMA: a thread owns a fixed
 // 16-byte channel vector, keeps its filter taps in registers and walks pixels; neighbouring taps are L1/L2 hits.
 #include "common.h"
+#include "det.h"
 #include <type_traits>
 #include "bn_tail.h"
 
@@ -59,6 +60,7 @@ struct DwArgs {
   int cpv, rows_pb;
   long rows_per_block;
   int stat_slots;
+  long part_stride;      // filter gradient, ordered mode (det.h): workgroup x adds into dw + x * part_stride instead of the shared dw
 };
 
 // MAXT = taps kept in registers (9 for 3x3)
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a, int d
   }
   {
     const int nch = min(cw, a.cpv - (int)blockIdx.y * 256) * VEC;        // channels owned by this workgroup
-    float* base = dw + (long)blockIdx.y * 256 * VEC * Tn;
+    float* base = dw + (long)blockIdx.x * a.part_stride + (long)blockIdx.y * 256 * VEC * Tn;
     for (int e = threadIdx.x; e < nch * Tn; e += 256) {                  // consecutive lanes -> consecutive addresses
       const int ch = e / Tn, t = e - ch * Tn;
       atomicAdd(base + e, red[ch / VEC][t * VEC + (ch % VEC)]);
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad3x3_f16_kernel(const DwArgs a
     __syncthreads();
   }
   const int nch = min(cw, a.cpv - (int)blockIdx.y * 256) * VEC;
-  float* base = dw + (long)blockIdx.y * 256 * VEC * 9;
+  float* base = dw + (long)blockIdx.x * a.part_stride + (long)blockIdx.y * 256 * VEC * 9;
   for (int e = threadIdx.x; e < nch * 9; e += 256) {
     const int ch = e / 9, t = e - ch * 9;
     atomicAdd(base + e, red[ch / VEC][t * VEC + (ch % VEC)]);
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const DwArgs a, int aux_ld, 
     __syncthreads();
     for (int e = threadIdx.x; e < 9 * C; e += 256) {          // dw layout [c][t]: consecutive lanes -> consecutive addresses
       const int ch = e / 9, t = e - ch * 9;
-      atomicAdd(dw + e, red[t * C + ch]);
+      atomicAdd(dw + (long)blockIdx.x * a.part_stride + e, red[t * C + ch]);
     }
   }
 }
@@ -574,22 +576,32 @@ static int dwconv_fwd_tail(const sy11_conv_desc* d, const void* x, const void* w
   int rc = dw_setup(d, a, vec, x, d->x_ld, y, d->y_ld, (long)d->B * d->OH * d->OW, 16, grid);
   if (rc) return rc;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  DetPartials dp;                                             // ordered mode (det.h): one partial statistics row per workgroup
+  const bool det = stat_sum && sy11_det(2) && !tail.ticket;
+  auto det_begin = [&](long rows) -> bool {
+    if (!dp.acquire(st, 2, rows, d->C)) return false;
+    a.stat_sum = dp.buf(0); a.stat_sq = dp.buf(1); a.stat_slots = (int)rows;
+    return true;
+  };
+  auto det_end = [&]() -> int { const int r = dp.fold(0, stat_sum); return r ? r : dp.fold(1, stat_sq); };
   if (dw3x3_ok(d, vec)) {
     int run, rpr; unsigned g;
     dw3x3_geom(d, a.cpv, &run, &rpr, &g, 1024);               // every workgroup ends with 2*C statistic atomics
+    if (det && !det_begin(g)) SY11_FAIL(SY11_ELAUNCH, "dwconv_fwd: ordered-reduction workspace unavailable");
     SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 0>), dim3(g), dim3(256), (2 * d->C + 256 * 2 * (16 / (int)sizeof(T))) * sizeof(float), st, a, 0,
                                                          (float*)nullptr, run, rpr, tail));
     SY11_LAUNCH_CHECK("dwconv_fwd");
     *tail_done = tail.ticket != nullptr && stat_sum != nullptr;
-    return SY11_OK;
+    return det ? det_end() : SY11_OK;
   }
+  if (det && !det_begin(grid.x)) SY11_FAIL(SY11_ELAUNCH, "dwconv_fwd: ordered-reduction workspace unavailable");
   SY11_DISPATCH_DTYPE(d->dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
     if (vec) hipLaunchKernelGGL((dwconv_fwd_kernel<T, VE, 9>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dwconv_fwd_kernel<T, 1, 9>), grid, dim3(256), 0, st, a);
   });
   SY11_LAUNCH_CHECK("dwconv_fwd");
-  return SY11_OK;
+  return det ? det_end() : SY11_OK;
 }
 
 int sy11_dwconv_dgrad_impl(const sy11_conv_desc* d, const void* dy, int dy_ld, const void* w, void* dx, hipStream_t st) {
@@ -625,6 +637,16 @@ extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, cons
   int rc = dw_setup(d, a, vec, x, d->x_ld, dy, dy_ld, (long)d->B * d->OH * d->OW, 32, grid);
   if (rc) return rc;
   a.x = x; a.y = (void*)dy;
+  DetPartials dp;                                             // ordered mode (det.h): one partial dW row per workgroup column x
+  const bool det = sy11_det(2);
+  float* const dw_out = dw;
+  const int ncol = d->C * d->KH * d->KW;
+  auto det_begin = [&](long rows) -> bool {
+    if (rows <= 1) return true;
+    if (!dp.acquire(st, 1, rows, ncol)) return false;
+    dw = dp.buf(0); a.part_stride = ncol;
+    return true;
+  };
   // the windowed walk (3 loads per pixel instead of 9) also wins here since its 9 x VEC partial sums per thread are folded through a
   // parking area instead of LDS atomics (r02, tools/dw_micro.py: 75 -> 64 us on 80x80x128, 51 -> 42 on 40x40x256, 32 -> 22 on 20x20x256)
   static int win_wgrad = -1;
@@ -632,11 +654,13 @@ extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, cons
   if (win_wgrad && dw3x3_ok(d, vec)) {
     int run, rpr; unsigned g;
     dw3x3_geom(d, a.cpv, &run, &rpr, &g, 512);                // every workgroup ends with 9*C filter-gradient atomics
+    if (det && !det_begin(g)) SY11_FAIL(SY11_ELAUNCH, "dwconv_wgrad: ordered-reduction workspace unavailable");
     SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3x3_kernel<T, 16 / (int)sizeof(T), 2>), dim3(g), dim3(256), (9 * d->C + 256 * 3 * (16 / (int)sizeof(T))) * sizeof(float), st, a, dy_ld, dw,
                                                          run, rpr, BnTailDev{}));
     SY11_LAUNCH_CHECK("dwconv_wgrad");
-    return SY11_OK;
+    return dp.base ? dp.fold(0, dw_out) : SY11_OK;
   }
+  if (det && !det_begin(grid.x)) SY11_FAIL(SY11_ELAUNCH, "dwconv_wgrad: ordered-reduction workspace unavailable");
   SY11_DISPATCH_DTYPE(d->dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
     if (vec && std::is_same<T, _Float16>::value && d->KH == 3 && d->KW == 3) hipLaunchKernelGGL(dwconv_wgrad3x3_f16_kernel, grid, dim3(256), 0, st, a, dy_ld, dw);
@@ -644,7 +668,7 @@ extern "C" int sy11_conv2d_wgrad_dw(const sy11_conv_desc* d, const void* x, cons
     else hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 1, 9>), grid, dim3(256), 0, st, a, dy_ld, dw);
   });
   SY11_LAUNCH_CHECK("dwconv_wgrad");
-  return SY11_OK;
+  return dp.base ? dp.fold(0, dw_out) : SY11_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ stem (Cin = 3, NCHW f32 in)
@@ -663,13 +687,12 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
   constexpr int ROWS = ROWB + 16;                   // padded LDS row (keeps 16-byte stores off one bank group)
   constexpr int CP = ROWB / 16;                     // 16-byte chunks per pixel
   __shared__ float sw[27][NMAX];
-  __shared__ float red[2][NMAX];
+  __shared__ float red[4][2][NMAX];                 // [wave][sum | sumsq][channel]: folded in wave order (no LDS atomics)
   __shared__ __attribute__((aligned(16))) unsigned char stage[256 * ROWS];
   for (int i = threadIdx.x; i < 27 * NMAX; i += 256) {
     const int k = i / NMAX, n = i - k * NMAX;          // k = (r*3+s)*3 + c  (filter layout [n][r][s][c])
     sw[k][n] = n < a.N ? ElemTraits<T>::to_f(((const T*)a.w)[n * 27 + k]) : 0.f;
   }
-  if (threadIdx.x < 2 * NMAX) ((float*)red)[threadIdx.x] = 0.f;
   __syncthreads();
   const int M = a.B * a.OH * a.OW;
   const int m = blockIdx.x * 256 + threadIdx.x;
@@ -701,13 +724,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
       float s1 = ok ? acc[n] : 0.f, s2 = s1 * s1;
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0][n], s1); atomicAdd(&red[1][n], s2); }
+      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0][n] = s1; red[threadIdx.x >> 6][1][n] = s2; }
     }
     __syncthreads();
     if (threadIdx.x < a.N) {
       const long so = (long)(blockIdx.x % a.stat_slots) * a.N;
-      atomicAdd(a.stat_sum + so + threadIdx.x, red[0][threadIdx.x]);
-      atomicAdd(a.stat_sq + so + threadIdx.x, red[1][threadIdx.x]);
+      const int n = threadIdx.x;
+      atomicAdd(a.stat_sum + so + n, ((red[0][0][n] + red[1][0][n]) + red[2][0][n]) + red[3][0][n]);
+      atomicAdd(a.stat_sq + so + n, ((red[0][1][n] + red[1][1][n]) + red[2][1][n]) + red[3][1][n]);
     }
   }
 #pragma unroll
@@ -741,7 +765,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
 // dW[n][k] += sum_m dy[m][n] * patch[m][k]: stage 64 pixels of dy (64 x N) and patches (64 x 27) in LDS, each thread
 // owns up to 4 (n,k) outputs.
 template <typename T, int NMAX>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, int dy_ld, float* dw, long pix_per_block) {
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, int dy_ld, float* dw, long pix_per_block, long part_stride) {
   constexpr int BP = 64;
   constexpr int NOUT = (27 * NMAX + 255) / 256;
   __shared__ float sdy[BP][NMAX + 1];
@@ -792,7 +816,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, int d
     const int id = threadIdx.x + o * 256;
     if (id < 27 * NMAX) {
       const int n = id / 27, k = id - n * 27;
-      if (n < a.N) atomicAdd(dw + n * 27 + k, acc[o]);
+      if (n < a.N) atomicAdd(dw + (long)blockIdx.x * part_stride + n * 27 + k, acc[o]);
     }
   }
 }
@@ -838,10 +862,9 @@ __device__ __forceinline__ StemTap stem_tap(int k, const StemArgs& a) {
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a, const BnTailDev tail) {
   constexpr int N = 32 * NT, ROWB = N * 2, ROWS = ROWB + 16, CP = ROWB / 16;
-  __shared__ float red[2][N];
+  __shared__ float red[4][2][N];                    // [wave][sum | sumsq][channel]: folded in wave order (no LDS atomics)
   __shared__ __attribute__((aligned(16))) unsigned char stage[256 * ROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
-  if (tid < 2 * N) ((float*)red)[tid] = 0.f;
   ss16x8 wf[NT][2];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -929,7 +952,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a, const BnTa
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const float t1 = s1[nt] + __shfl_xor(s1[nt], 32), t2 = s2[nt] + __shfl_xor(s2[nt], 32);
-      if (half == 0) { atomicAdd(&red[0][nt * 32 + col], t1); atomicAdd(&red[1][nt * 32 + col], t2); }
+      if (half == 0) { red[wave][0][nt * 32 + col] = t1; red[wave][1][nt * 32 + col] = t2; }
     }
   }
   {
@@ -946,8 +969,8 @@ __global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a, const BnTa
     __syncthreads();
     if (tid < N) {
       const long so = (long)(blockIdx.x % a.stat_slots) * N;
-      atomicAdd(a.stat_sum + so + tid, red[0][tid]);
-      atomicAdd(a.stat_sq + so + tid, red[1][tid]);
+      atomicAdd(a.stat_sum + so + tid, ((red[0][0][tid] + red[1][0][tid]) + red[2][0][tid]) + red[3][0][tid]);
+      atomicAdd(a.stat_sq + so + tid, ((red[0][1][tid] + red[1][1][tid]) + red[2][1][tid]) + red[3][1][tid]);
     }
     if (tail.ticket) bn_tail_run(tail, a.stat_sum, a.stat_sq, a.stat_slots, N, gridDim.x);
   }
@@ -956,7 +979,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mma(const StemArgs a, const BnTa
 // dW[n][k] += sum_p dy[p][n] * patch[p][k]: pixels are the MFMA reduction.  A = dy^T through the transposing LDS read
 // (32-pixel x N tile per wave, row stride = 64 mod 256 bytes), B = patch column k = lane, gathered from the image.
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* dw, int pix_per_block) {
+__global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* dw, int pix_per_block, long part_stride) {
   constexpr int N = 32 * NT, ROW = (N * 2) % 256 == 64 ? N * 2 : N * 2 + 64, CPR = N / 8;
   __shared__ __attribute__((aligned(16))) unsigned char sdy[4 * 32 * ROW];
   __shared__ float sacc[NT][32][33];
@@ -1029,14 +1052,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* d
       }
   }
   __syncthreads();
+  for (int w = 0; w < 4; ++w) {                         // the four waves add their tiles one after the other: a fixed order
+    if (wave == w) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) atomicAdd(&sacc[nt][(e & 3) + 8 * (e >> 2) + 4 * half][col], acc[nt][e]);
-  __syncthreads();
+        for (int e = 0; e < 16; ++e) sacc[nt][(e & 3) + 8 * (e >> 2) + 4 * half][col] += acc[nt][e];
+    }
+    __syncthreads();
+  }
   for (int i = tid; i < N * 27; i += 256) {
     const int n = i / 27, k = i - n * 27;
-    atomicAdd(dw + i, sacc[n >> 5][n & 31][k]);
+    atomicAdd(dw + (long)blockIdx.x * part_stride + i, sacc[n >> 5][n & 31][k]);
   }
 }
 
@@ -1079,6 +1106,13 @@ static int stem_fwd_tail(const sy11_conv_desc* d, const float* x_nchw, const voi
   const long M = (long)d->B * d->OH * d->OW;
   dim3 grid((unsigned)((M + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  DetPartials dp;                                             // ordered mode (det.h): one partial statistics row per workgroup
+  const bool det = stat_sum && sy11_det(2) && !tail.ticket;
+  if (det) {
+    if (!dp.acquire(st, 2, grid.x, d->N)) SY11_FAIL(SY11_ELAUNCH, "stem_conv_fwd: ordered-reduction workspace unavailable");
+    a.stat_sum = dp.buf(0); a.stat_sq = dp.buf(1); a.stat_slots = (int)grid.x;
+  }
+  auto det_end = [&]() -> int { const int r = dp.fold(0, stat_sum); return r ? r : dp.fold(1, stat_sq); };
   if (d->dtype != SY11_F32 && (d->N == 32 || d->N == 64) && d->y_ld == d->N && ((uintptr_t)y & 15) == 0 &&
       (long)d->B * 3 * d->IH * d->IW < (1L << 31) && (long)(d->OW + 64) * d->OW < (1L << 20) && (long)(d->OH + 64) * d->OH < (1L << 20)) {
     a.mag_ow = (unsigned)(((1u << 20) + d->OW - 1) / d->OW);
@@ -1089,13 +1123,13 @@ static int stem_fwd_tail(const sy11_conv_desc* d, const float* x_nchw, const voi
     });
     SY11_LAUNCH_CHECK("stem_conv_fwd");
     *tail_done = tail.ticket != nullptr && stat_sum != nullptr;
-    return SY11_OK;
+    return det ? det_end() : SY11_OK;
   }
   if (d->N <= 16) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 16>), grid, block, 0, st, a)); }
   else if (d->N <= 32) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 32>), grid, block, 0, st, a)); }
   else { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_fwd_kernel<T, 64>), grid, block, 0, st, a)); }
   SY11_LAUNCH_CHECK("stem_conv_fwd");
-  return SY11_OK;
+  return det ? det_end() : SY11_OK;
 }
 
 extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw, const void* dy, int32_t dy_ld, float* dw,
@@ -1122,16 +1156,30 @@ extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw
     if (nb > 512) nb = 512;
     const int ppbm = (int)(((M + nb - 1) / nb + 127) / 128 * 128);
     dim3 gm((unsigned)((M + ppbm - 1) / ppbm));
+    DetPartials dp;                                           // ordered mode (det.h): one partial dW row per workgroup
+    float* dwk = dw;
+    long pstride = 0;
+    if (sy11_det(2) && gm.x > 1) {
+      if (!dp.acquire(st, 1, gm.x, d->N * 27)) SY11_FAIL(SY11_ELAUNCH, "stem_conv_wgrad: ordered-reduction workspace unavailable");
+      dwk = dp.buf(0); pstride = d->N * 27;
+    }
     SY11_DISPATCH_DTYPE(d->dtype, T, {
-      if (d->N == 32) hipLaunchKernelGGL((stem_wgrad_mma<T, 1>), gm, block, 0, st, am, dw, ppbm);
-      else hipLaunchKernelGGL((stem_wgrad_mma<T, 2>), gm, block, 0, st, am, dw, ppbm);
+      if (d->N == 32) hipLaunchKernelGGL((stem_wgrad_mma<T, 1>), gm, block, 0, st, am, dwk, ppbm, pstride);
+      else hipLaunchKernelGGL((stem_wgrad_mma<T, 2>), gm, block, 0, st, am, dwk, ppbm, pstride);
     });
     SY11_LAUNCH_CHECK("stem_conv_wgrad");
-    return SY11_OK;
+    return dp.base ? dp.fold(0, dw) : SY11_OK;
   }
-  if (d->N <= 16) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 16>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
-  else if (d->N <= 32) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 32>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
-  else { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 64>), grid, block, 0, st, a, dy_ld, dw, ppb)); }
+  DetPartials dp;
+  float* dwk = dw;
+  long pstride = 0;
+  if (sy11_det(2) && grid.x > 1) {
+    if (!dp.acquire(st, 1, grid.x, d->N * 27)) SY11_FAIL(SY11_ELAUNCH, "stem_conv_wgrad: ordered-reduction workspace unavailable");
+    dwk = dp.buf(0); pstride = d->N * 27;
+  }
+  if (d->N <= 16) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 16>), grid, block, 0, st, a, dy_ld, dwk, ppb, pstride)); }
+  else if (d->N <= 32) { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 32>), grid, block, 0, st, a, dy_ld, dwk, ppb, pstride)); }
+  else { SY11_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((stem_wgrad_kernel<T, 64>), grid, block, 0, st, a, dy_ld, dwk, ppb, pstride)); }
   SY11_LAUNCH_CHECK("stem_conv_wgrad");
-  return SY11_OK;
+  return dp.base ? dp.fold(0, dw) : SY11_OK;
 }

@@ -6,6 +6,7 @@
 // per-channel parameters are loaded once and every global access of a wave is a run of full 16-byte lanes.
 #include "common.h"
 #include "tune.h"
+#include "det.h"
 
 template <typename T, int VEC> struct Vec {
   T v[VEC];
@@ -338,15 +339,27 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
   // at most 4096 blocks (each ends in a tree reduction and 2 x C atomics)
   const long nb4 = (M + g.rows_pb * 4L - 1) / (g.rows_pb * 4L);
   const RowWalk w = row_walk(M, g.rows_pb, 4, nb4 > 640 ? 2 : 1, 4096);
-  const int slots = sum_slots > 1 ? sum_slots : 1;
+  int slots = sum_slots > 1 ? sum_slots : 1;
   dim3 grid(w.grid, g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
+  DetPartials dp;                                   // ordered mode (det.h): one partial row per workgroup x, folded into row 0 of the caller's slots
+  float* const sum_g_out = sum_g;
+  float* const sum_gx_out = sum_gx;
+  const bool det = sy11_det(4) && w.grid > 1;
+  if (det) {
+    if (!dp.acquire(st, 2, w.grid, C)) SY11_FAIL(SY11_ELAUNCH, "bn_act_bwd_reduce: ordered-reduction workspace unavailable");
+    sum_g = dp.buf(0); sum_gx = dp.buf(1); slots = w.grid;
+  }
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
     if (v) { if (silu) SY11_BNR(VE, true); else SY11_BNR(VE, false); }
     else { if (silu) SY11_BNR(1, true); else SY11_BNR(1, false); }
   });
   SY11_LAUNCH_CHECK("bn_act_bwd_reduce");
+  if (det) {
+    const int rc = dp.fold(0, sum_g_out);
+    return rc ? rc : dp.fold(1, sum_gx_out);
+  }
   return SY11_OK;
 }
 
@@ -787,5 +800,142 @@ extern "C" int sy11_cast(int32_t src_dtype, int32_t dst_dtype, int64_t n, const 
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(src_dtype, S, SY11_DISPATCH_DTYPE(dst_dtype, D, hipLaunchKernelGGL((cast_kernel<S, D>), dim3((unsigned)g), dim3(256), 0, st, (long)n, (const S*)src, (D*)dst)));
   SY11_LAUNCH_CHECK("cast");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ bias gradient + cast
+// Backward of a bare nn.Conv2d with bias whose output is f32 (Detect's last 1x1 convs, head.py:44-55): the f32 gradient of the
+// logits dz (M rows x N channels) becomes (a) the bias gradient  dbias[c] += sum_m dz[m][c]  and (b) the 16-bit operand dy of the
+// filter- / input-gradient kernels, zero-padded to `npad` channels (a whole number of 16-byte vectors: nc = 2 -> 8).  One pass over
+// dz instead of three fills, a BatchNorm-reduce launch, a zero fill and a strided copy.  A workgroup owns a contiguous run of rows;
+// thread t keeps channel t % npad (the thread count is the largest multiple of npad <= 256, so a wave's loads are contiguous); the
+// per-thread sums meet in LDS and are folded in row-group order: ONE ordered partial per workgroup and channel, added atomically
+// into dbias or — `partials` != NULL (ordered-reduction mode) — stored to partials[workgroup][N] for a fixed-order fold kernel.
+template <typename D, int VEC>
+__global__ __launch_bounds__(256) void bias_grad_cast_kernel(long M, int N, int npad, const float* __restrict__ dz, int dz_ld, D* __restrict__ dy,
+                                                             float* dbias, float* partials, long rows_per_block) {
+  // VEC channels per thread (4 when N, npad, dz_ld are multiples of 4: 16-byte loads, 8-byte stores), else 1
+  __shared__ float red[256 * VEC];
+  const int cpr = npad / VEC;                                // channel vectors per row
+  const int groups = blockDim.x / cpr;                       // row groups of this block
+  const int cv = threadIdx.x % cpr, rg = threadIdx.x / cpr, c = cv * VEC;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+  constexpr int U = 4;                                       // rows in flight per thread
+  for (long r = r0 + rg; r < r1; r += (long)groups * U) {
+    float v[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long rr = r + (long)u * groups;
+      const bool live = rr < r1 && c < N;
+      if (VEC == 4) {
+        const float4 q = live ? *(const float4*)(dz + rr * dz_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u][0] = q.x; v[u][1 % VEC] = q.y; v[u][2 % VEC] = q.z; v[u][3 % VEC] = q.w;
+      } else {
+        v[u][0] = live ? dz[rr * dz_ld + c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long rr = r + (long)u * groups;
+      if (rr < r1) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] += v[u][i];
+        vstore<D, VEC>(dy + rr * npad + c, v[u]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) red[threadIdx.x * VEC + i] = s[i];
+  __syncthreads();
+  if (rg == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (c + i >= N) continue;
+      float t = 0.f;
+      for (int g = 0; g < groups; ++g) t += red[(g * cpr + cv) * VEC + i];        // row groups folded in index order
+      if (partials) partials[(long)blockIdx.x * N + c + i] = t;
+      else if (dbias) atomicAdd(dbias + c + i, t);
+    }
+  }
+}
+// out[c] += sum over `rows` partial rows, in a fixed order: one workgroup per channel, thread t takes rows t, t + 256, ..., then a
+// binary tree over the 256 threads
+__global__ __launch_bounds__(256) void fold_rows_kernel(int rows, int N, const float* __restrict__ partials, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  float t = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) t += partials[(long)r * N + c];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int h = 128; h >= 1; h >>= 1) {
+    if (threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] += red[0];
+}
+
+extern "C" int sy11_bias_grad_cast(int32_t dtype, int64_t M, int32_t N, int32_t npad, const float* dz, int32_t dz_ld, void* dy, float* dbias,
+                                   float* partials, int32_t partial_rows, void* stream) {
+  SY11_REQUIRE(dtype_ok(dtype) && M > 0 && N > 0 && npad >= N && npad <= 256 && dz && dy && dz_ld >= N, "bias_grad_cast: bad argument (N <= npad <= 256)");
+  const bool v4 = N % 4 == 0 && npad % 4 == 0 && dz_ld % 4 == 0 && ((uintptr_t)dz & 15) == 0 && ((uintptr_t)dy & 15) == 0;
+  const int cpr = v4 ? npad / 4 : npad;
+  const int threads = 256 / cpr * cpr;
+  // few, long workgroups: every workgroup ends in N same-line adds (atomic mode) or one partial row (ordered mode)
+  long blocks = (M + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  if (partials) {
+    SY11_REQUIRE(dbias && partial_rows > 0, "bias_grad_cast: ordered mode needs dbias and a partial-row count");
+    if (blocks > partial_rows) blocks = partial_rows;
+  }
+  const long rpb = (M + blocks - 1) / blocks;
+  blocks = (M + rpb - 1) / rpb;
+  hipStream_t st = (hipStream_t)stream;
+  SY11_DISPATCH_DTYPE(dtype, D, {
+    if (v4) hipLaunchKernelGGL((bias_grad_cast_kernel<D, 4>), dim3((unsigned)blocks), dim3(threads), 0, st, (long)M, N, npad, dz, dz_ld, (D*)dy, dbias, partials, rpb);
+    else hipLaunchKernelGGL((bias_grad_cast_kernel<D, 1>), dim3((unsigned)blocks), dim3(threads), 0, st, (long)M, N, npad, dz, dz_ld, (D*)dy, dbias, partials, rpb);
+  });
+  if (partials) hipLaunchKernelGGL(fold_rows_kernel, dim3(N), dim3(256), 0, st, (int)blocks, N, (const float*)partials, dbias);
+  SY11_LAUNCH_CHECK("bias_grad_cast");
+  return SY11_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ordered row fold (det.h)
+// One stage: rows [64 * y, 64 * y + 64) of `src` -> row y of `dst` (ACCUM: added onto dst row 0 instead, used by the last stage
+// with gridDim.y == 1).  Block = 64 columns x 4 row lanes; lane q adds rows q, q + 4, ... of its 64-row group in order, the four
+// lanes are folded in index order: a fixed tree, whatever the launch timing.
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void fold_stage_kernel(long rows, int N, const float* __restrict__ src, long stride, float* __restrict__ dst, long group) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long r0 = (long)blockIdx.y * group, r1 = r0 + group < rows ? r0 + group : rows;
+  float t = 0.f;
+  if (c < N)
+    for (long r = r0 + q; r < r1; r += 4) t += src[r * stride + c];
+  red[q][cl] = t;
+  __syncthreads();
+  if (q == 0 && c < N) {
+    const float tot = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    if (ACCUM) dst[c] += tot; else dst[(long)blockIdx.y * N + c] = tot;
+  }
+}
+int sy11_fold_rows_ordered(long rows, int N, const float* partials, long stride, float* out, float* scratch, hipStream_t st) {
+  if (rows <= 0 || N <= 0) return SY11_OK;
+  const float* src = partials;
+  long sstride = stride;
+  float* ping = scratch;
+  while (rows > 256) {                                   // 64 rows -> 1 per stage until one workgroup column can finish
+    const long nr = (rows + 63) / 64;
+    float* dst = ping;
+    hipLaunchKernelGGL((fold_stage_kernel<false>), dim3(cdiv(N, 64), (unsigned)nr), dim3(256), 0, st, rows, N, src, sstride, dst, 64L);
+    src = dst; sstride = N; rows = nr;
+    ping = dst + nr * N;                                 // next stage writes behind this one (scratch holds rows/64 + 64 rows)
+  }
+  hipLaunchKernelGGL((fold_stage_kernel<true>), dim3(cdiv(N, 64), 1), dim3(256), 0, st, rows, N, src, sstride, out, rows);
+  SY11_LAUNCH_CHECK("fold_rows");
   return SY11_OK;
 }

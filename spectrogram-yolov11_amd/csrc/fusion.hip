@@ -11,6 +11,7 @@
 // two tiny kernels (3x3 map + sigmoid, the gate vector), and one combine pass; the backward mirrors it.
 // Layout: NHWC views (pointer + pixel stride), a group of LP = C / VEC lanes owns one pixel (VEC = 16 bytes of channels).
 #include "common.h"
+#include "det.h"
 
 template <typename T, int VEC>
 __device__ __forceinline__ void fload(const T* p, float* f) {
@@ -45,11 +46,9 @@ static bool fusion_view_ok(const void* p, int ld, int dtype) {
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void fusion_stats_kernel(int HW, int C, int LP, const T* __restrict__ x, int x_ld, float* __restrict__ mm,
                                                            unsigned short* __restrict__ amax, float* __restrict__ sq, int sq_ld) {
-  extern __shared__ float red[];                       // [C] sum of squares of this block
+  extern __shared__ float red[];                       // [C] sum of squares of this block, then a [256][VEC] parking area
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cl = tid % LP, sub = tid / LP, ppb = 256 / LP;
-  for (int i = tid; i < C; i += 256) red[i] = 0.f;
-  __syncthreads();
   float sacc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) sacc[i] = 0.f;
@@ -78,10 +77,17 @@ __global__ __launch_bounds__(256) void fusion_stats_kernel(int HW, int C, int LP
       amax[pix] = (unsigned short)mi;
     }
   }
+  // every thread parks its VEC partial sums; thread c then adds the ppb rows of channel c in row order (no LDS atomics)
+  float* park = red + C;
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) atomicAdd(&red[cl * VEC + i], sacc[i]);
+  for (int i = 0; i < VEC; ++i) park[tid * VEC + i] = sacc[i];
   __syncthreads();
-  for (int i = tid; i < C; i += 256) atomicAdd(sq + (long)b * sq_ld + i, red[i]);
+  for (int i = tid; i < C; i += 256) {
+    const int cv = i / VEC, j = i - cv * VEC;
+    float t = 0.f;
+    for (int k = 0; k < ppb; ++k) t += park[(k * LP + cv) * VEC + j];
+    atomicAdd(sq + (long)b * sq_ld + i, t);
+  }
 }
 
 extern "C" int sy11_fusion_stats(int32_t dtype, int32_t B, int32_t HW, int32_t C, const void* x, int32_t x_ld, float* mm,
@@ -94,8 +100,9 @@ extern "C" int sy11_fusion_stats(int32_t dtype, int32_t B, int32_t HW, int32_t C
   const int ppb = 256 / lp;
   int gx = cdiv(HW, ppb * 8);
   if (gx > 512) gx = 512;
+  if (sy11_det(32)) gx = 1;                              // ordered mode: one workgroup per image owns sq[b][:] (det.h)
   dim3 grid(gx, B), block(256);
-  SY11_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fusion_stats_kernel<T, 16 / (int)sizeof(T)>), grid, block, C * sizeof(float), (hipStream_t)stream, HW,
+  SY11_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fusion_stats_kernel<T, 16 / (int)sizeof(T)>), grid, block, (C + 256 * (16 / (int)sizeof(T))) * sizeof(float), (hipStream_t)stream, HW,
                                                    C, lp, (const T*)x, x_ld, mm, amax, sq, sq_ld));
   SY11_LAUNCH_CHECK("fusion_stats");
   return SY11_OK;
@@ -134,10 +141,8 @@ extern "C" int sy11_sab_map_fwd(int32_t B, int32_t H, int32_t W, const float* mm
 // dpre = dS * S * (1 - S);  dmm[p][ch] = sum_taps dpre[p - tap] * w[tap][ch];  dw[tap][ch] += sum_p dpre[p] * mm[p + tap][ch]
 __global__ __launch_bounds__(256) void sab_map_bwd_kernel(int B, int H, int W, const float* __restrict__ dS, const float* __restrict__ S,
                                                           const float* __restrict__ mm, const float* __restrict__ w, float* __restrict__ dmm,
-                                                          float* dw) {
-  __shared__ float red[18];
-  if (threadIdx.x < 18) red[threadIdx.x] = 0.f;
-  __syncthreads();
+                                                          float* dw, long part_stride) {
+  __shared__ float red[4 * 18];
   const long n = (long)B * H * W;
   const long pix = (long)blockIdx.x * 256 + threadIdx.x;
   const bool live = pix < n;
@@ -175,19 +180,29 @@ __global__ __launch_bounds__(256) void sab_map_bwd_kernel(int B, int H, int W, c
     float v = part[i];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&red[i], v);
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 18 + i] = v;       // [wave][18], folded in wave order below
   }
   __syncthreads();
-  if (threadIdx.x < 18) atomicAdd(dw + threadIdx.x, red[threadIdx.x]);
+  if (threadIdx.x < 18)
+    atomicAdd(dw + (long)blockIdx.x * part_stride + threadIdx.x,
+              ((red[threadIdx.x] + red[18 + threadIdx.x]) + red[36 + threadIdx.x]) + red[54 + threadIdx.x]);
 }
 
 extern "C" int sy11_sab_map_bwd(int32_t B, int32_t H, int32_t W, const float* dS, const float* S, const float* mm, const float* w,
                                 float* dmm, float* dw, void* stream) {
   SY11_REQUIRE(B > 0 && H > 0 && W > 0 && dS && S && mm && w && dmm && dw, "sab_map_bwd: bad argument");
   const long n = (long)B * H * W;
-  hipLaunchKernelGGL(sab_map_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, H, W, dS, S, mm, w, dmm, dw);
+  const long nb = (n + 255) / 256;
+  DetPartials dp;                                      // ordered mode (det.h): one partial dw[18] row per workgroup
+  float* dwk = dw;
+  long pstride = 0;
+  if (sy11_det(32) && nb > 1) {
+    if (!dp.acquire((hipStream_t)stream, 1, nb, 18)) SY11_FAIL(SY11_ELAUNCH, "sab_map_bwd: ordered-reduction workspace unavailable");
+    dwk = dp.buf(0); pstride = 18;
+  }
+  hipLaunchKernelGGL(sab_map_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, H, W, dS, S, mm, w, dmm, dwk, pstride);
   SY11_LAUNCH_CHECK("sab_map_bwd");
-  return SY11_OK;
+  return dp.base ? dp.fold(0, dw) : SY11_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ GCT gate vector
@@ -230,9 +245,10 @@ extern "C" int sy11_gct_gate_fwd(int32_t B, int32_t Ct, const float* sq, const f
 __global__ __launch_bounds__(256) void gct_gate_bwd_kernel(int Ct, const float* __restrict__ sq, const float* __restrict__ alpha,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            const float* __restrict__ dG, float* __restrict__ q, float* dalpha, float* dgamma,
-                                                           float* dbeta) {
+                                                           float* dbeta, long part_stride) {
   __shared__ float sh[4];
   const int b = blockIdx.x;
+  const long po = (long)b * part_stride;                 // ordered mode: image b adds into its own partial row
   float part = 0.f;
   for (int c = threadIdx.x; c < Ct; c += 256) {
     const float e = sqrtf(sq[(long)b * Ct + c] + eps) * alpha[c];
@@ -256,17 +272,29 @@ __global__ __launch_bounds__(256) void gct_gate_bwd_kernel(int Ct, const float* 
     const float dz = dG[(long)b * Ct + c] * (1.f - t * t);
     const float de = dz * gamma[c] * r + dm * 2.f * e / (float)Ct;
     q[(long)b * Ct + c] = de * alpha[c] / root;          // ds = de * alpha / (2 root),  dx = 2 x ds
-    atomicAdd(dbeta + c, dz);
-    atomicAdd(dgamma + c, dz * e * r);
-    atomicAdd(dalpha + c, de * root);
+    atomicAdd(dbeta + po + c, dz);
+    atomicAdd(dgamma + po + c, dz * e * r);
+    atomicAdd(dalpha + po + c, de * root);
   }
 }
 
 extern "C" int sy11_gct_gate_bwd(int32_t B, int32_t Ct, const float* sq, const float* alpha, const float* gamma, const float* beta,
                                  float eps, const float* dG, float* q, float* dalpha, float* dgamma, float* dbeta, void* stream) {
   SY11_REQUIRE(B > 0 && Ct > 0 && sq && alpha && gamma && beta && dG && q && dalpha && dgamma && dbeta, "gct_gate_bwd: bad argument");
-  hipLaunchKernelGGL(gct_gate_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Ct, sq, alpha, gamma, beta, eps, dG, q, dalpha, dgamma, dbeta);
+  DetPartials dp;                                      // ordered mode (det.h): one partial row per image for each of the three gradients
+  float *pa = dalpha, *pg = dgamma, *pb = dbeta;
+  long pstride = 0;
+  if (sy11_det(32) && B > 1) {
+    if (!dp.acquire((hipStream_t)stream, 3, B, Ct)) SY11_FAIL(SY11_ELAUNCH, "gct_gate_bwd: ordered-reduction workspace unavailable");
+    pa = dp.buf(0); pg = dp.buf(1); pb = dp.buf(2); pstride = Ct;
+  }
+  hipLaunchKernelGGL(gct_gate_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Ct, sq, alpha, gamma, beta, eps, dG, q, pa, pg, pb, pstride);
   SY11_LAUNCH_CHECK("gct_gate_bwd");
+  if (dp.base) {
+    int rc = dp.fold(0, dalpha);
+    if (!rc) rc = dp.fold(1, dgamma);
+    return rc ? rc : dp.fold(2, dbeta);
+  }
   return SY11_OK;
 }
 
@@ -330,11 +358,9 @@ extern "C" int sy11_fusion_combine(int32_t dtype, int32_t B, int32_t HW, int32_t
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void fusion_bwd_reduce_kernel(int HW, int C, int LP, const T* __restrict__ dout, int dout_ld, const T* __restrict__ x,
                                                                 int x_ld, float* __restrict__ dG, int dg_ld, float* __restrict__ dS) {
-  extern __shared__ float red[];
+  extern __shared__ float red[];                       // [C] (unused head) + [256][VEC] parking area
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cl = tid % LP, sub = tid / LP, ppb = 256 / LP;
-  for (int i = tid; i < C; i += 256) red[i] = 0.f;
-  __syncthreads();
   float gacc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) gacc[i] = 0.f;
@@ -353,10 +379,16 @@ __global__ __launch_bounds__(256) void fusion_bwd_reduce_kernel(int HW, int C, i
     for (int o = LP >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if (cl == 0) dS[pix] = s;
   }
+  float* park = red + C;
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) atomicAdd(&red[cl * VEC + i], gacc[i]);
+  for (int i = 0; i < VEC; ++i) park[tid * VEC + i] = gacc[i];
   __syncthreads();
-  for (int i = tid; i < C; i += 256) atomicAdd(dG + (long)b * dg_ld + i, red[i]);
+  for (int i = tid; i < C; i += 256) {
+    const int cv = i / VEC, j = i - cv * VEC;
+    float t = 0.f;
+    for (int k = 0; k < ppb; ++k) t += park[(k * LP + cv) * VEC + j];
+    atomicAdd(dG + (long)b * dg_ld + i, t);
+  }
 }
 
 extern "C" int sy11_fusion_bwd_reduce(int32_t dtype, int32_t B, int32_t HW, int32_t C, const void* dout, int32_t dout_ld, const void* x,
@@ -368,8 +400,9 @@ extern "C" int sy11_fusion_bwd_reduce(int32_t dtype, int32_t B, int32_t HW, int3
   const int ppb = 256 / lp;
   int gx = cdiv(HW, ppb * 8);
   if (gx > 512) gx = 512;
+  if (sy11_det(32)) gx = 1;                              // ordered mode: one workgroup per image owns dG[b][:] (det.h)
   dim3 grid(gx, B), block(256);
-  SY11_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fusion_bwd_reduce_kernel<T, 16 / (int)sizeof(T)>), grid, block, C * sizeof(float), (hipStream_t)stream,
+  SY11_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fusion_bwd_reduce_kernel<T, 16 / (int)sizeof(T)>), grid, block, (C + 256 * (16 / (int)sizeof(T))) * sizeof(float), (hipStream_t)stream,
                                                    HW, C, lp, (const T*)dout, dout_ld, (const T*)x, x_ld, dG, dg_ld, dS));
   SY11_LAUNCH_CHECK("fusion_bwd_reduce");
   return SY11_OK;

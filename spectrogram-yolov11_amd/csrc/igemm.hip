@@ -18,6 +18,7 @@
 // (P - r*D)/S offsets of one output-parity class, output written with a pixel stride (oy*oy_mul+oy_add).
 #include "common.h"
 #include "tune.h"
+#include "det.h"
 #include "bn_tail.h"
 #include "igemm_args.h"
 #include <stdlib.h>
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
   static_assert(BN % RPP == 0 || BN < RPP, "pass geometry");
   __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE + 192 + 512];
-  __shared__ float s_red[2 * BN];                 // per-channel sum / sumsq of this tile (BN batch statistics)
+  __shared__ float s_red[WM * 2 * BN];           // BN batch statistics of this tile, [wave row wm][sum | sumsq][channel]: ordered fold, no LDS atomics
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of tiles
@@ -103,7 +104,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
-  for (int i = tid; i < 2 * BN; i += 256) s_red[i] = 0.f;
 
   constexpr int APASS = BM / RPP, BPASS = (BN + RPP - 1) / RPP;
   constexpr int ESZ = (int)sizeof(T);
@@ -483,15 +483,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
       const float s2 = ssq[j] + __shfl_xor(ssq[j], 32);
       if (fh == 0) {
         const int col = wn * (BN / WN) + j * 32 + frow;
-        atomicAdd(&s_red[col], s1);
-        atomicAdd(&s_red[BN + col], s2);
+        s_red[wm * 2 * BN + col] = s1;            // one row per wave row: the fold below adds them in index order (bit-reproducible)
+        s_red[wm * 2 * BN + BN + col] = s2;
       }
     }
     __syncthreads();
     if (tid < BN && bn0 + tid < a.N) {
       const long so = (long)(blockIdx.x % a.stat_slots) * a.stat_stride;
-      atomicAdd(a.stat_sum + so + bn0 + tid, s_red[tid]);
-      atomicAdd(a.stat_sq + so + bn0 + tid, s_red[BN + tid]);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < WM; ++r) { t1 += s_red[r * 2 * BN + tid]; t2 += s_red[r * 2 * BN + BN + tid]; }
+      atomicAdd(a.stat_sum + so + bn0 + tid, t1);
+      atomicAdd(a.stat_sq + so + bn0 + tid, t2);
     }
     if (a.tail.ticket) bn_tail_run(a.tail, a.stat_sum, a.stat_sq, a.stat_slots, a.stat_stride, gridDim.x);
   }
@@ -557,6 +560,15 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
   const long nwg = (long)cdiv(a.M, bm) * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg), block(256);
+  // ordered mode (det.h): statistics go to one partial row per workgroup (slot = workgroup index), folded in index order afterwards
+  DetPartials dp;
+  float* const stat_sum_out = a.stat_sum;
+  float* const stat_sq_out = a.stat_sq;
+  const bool det = a.stat_sum && sy11_det(1) && !a.tail.ticket;
+  if (det) {
+    if (!dp.acquire(st, 2, nwg, a.N)) SY11_FAIL(SY11_ELAUNCH, "igemm: ordered-reduction workspace unavailable (%ld x %d floats)", nwg, a.N);
+    a.stat_sum = dp.buf(0); a.stat_sq = dp.buf(1); a.stat_slots = (int)nwg; a.stat_stride = a.N;
+  }
   // 0 = 128-byte stages x2 (2 WG/CU), 1 = 64-byte stages x2 (4 WG/CU), 2 = 64-byte stages x4, 3 = 128-byte stages x3
   const int variant = cfg >= 12 ? 3 : (cfg >= 9 ? 2 : (cfg >= 4 ? 0 : 1));
   // epilogue specialisation: the common flag sets get branch-free code, anything else the runtime-flag build (EPI = -1)
@@ -598,6 +610,10 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
 #undef SY11_IGV
 #undef SY11_IG
   SY11_LAUNCH_CHECK("igemm");
+  if (det) {
+    const int rc = dp.fold(0, stat_sum_out);
+    return rc ? rc : dp.fold(1, stat_sq_out);
+  }
   return SY11_OK;
 }
 

@@ -9,6 +9,7 @@
 // LDS image = K/32 "planes" of [rows][64 bytes] (the stage layout of igemm.hip, same source-side XOR swizzle, same fragment
 // reads), so the MFMA core is identical.  Selected per layer by the first-call autotuner (tune.h) as one more candidate.
 #include "common.h"
+#include "det.h"
 
 typedef int p_rsrc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void p_lds_dma16(unsigned lds_addr, unsigned voff, p_rsrc_t rsrc) {
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void igemm1x1p_kernel(const P1x1Args a) {
   constexpr int ROWB = BN * 2, CPR = ROWB / 16;
   static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float s_red[2 * BN];
+  __shared__ float s_red[WM * 2 * BN];           // [wave row wm][sum | sumsq][channel]: ordered fold, no LDS atomics
   const int np = a.K >> 5;                                   // planes of 32 elements (64 bytes) of K
   unsigned char* sB = smem;                                  // [np][BN][64]
   unsigned char* sA = sB + np * B_PLANE;                     // [2][np][BM][64]
@@ -69,7 +70,6 @@ __global__ __launch_bounds__(256) void igemm1x1p_kernel(const P1x1Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int bn0 = blockIdx.y * BN;
-  for (int i = tid; i < 2 * BN; i += 256) s_red[i] = 0.f;
 
   const p_rsrc_t xr = p_make_rsrc(a.x, a.x_bytes), wr_ = p_make_rsrc(a.w, a.w_bytes);
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -203,15 +203,18 @@ __global__ __launch_bounds__(256) void igemm1x1p_kernel(const P1x1Args a) {
       const float s2 = ssq[j] + __shfl_xor(ssq[j], 32);
       if (fh == 0) {
         const int col = wn * (BN / WN) + j * 32 + frow;
-        atomicAdd(&s_red[col], s1);
-        atomicAdd(&s_red[BN + col], s2);
+        s_red[wm * 2 * BN + col] = s1;            // one row per wave row: the fold below adds them in index order (bit-reproducible)
+        s_red[wm * 2 * BN + BN + col] = s2;
       }
     }
     __syncthreads();
     if (tid < BN && bn0 + tid < a.N) {
       const long so = (long)((blockIdx.x + blockIdx.y) % a.stat_slots) * a.stat_stride;
-      atomicAdd(a.stat_sum + so + bn0 + tid, s_red[tid]);
-      atomicAdd(a.stat_sq + so + bn0 + tid, s_red[BN + tid]);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < WM; ++r) { t1 += s_red[r * 2 * BN + tid]; t2 += s_red[r * 2 * BN + BN + tid]; }
+      atomicAdd(a.stat_sum + so + bn0 + tid, t1);
+      atomicAdd(a.stat_sq + so + bn0 + tid, t2);
     }
   }
 }
@@ -232,6 +235,12 @@ int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, floa
   int gx = a.tiles_m < 256 ? a.tiles_m : 256;
   if (lds <= 72 * 1024 && a.tiles_m >= 1024) gx = 512;       // two resident workgroups per CU when LDS allows
   dim3 grid(gx, tiles_n), block(256);
+  DetPartials dp;                                   // ordered mode (det.h): slot = x + y is unique per (workgroup row, channel tile)
+  const bool det = stat_sum && (epi & 1) && sy11_det(1);
+  if (det) {
+    if (!dp.acquire(st, 2, gx + tiles_n, N)) SY11_FAIL(SY11_ELAUNCH, "igemm1x1p: ordered-reduction workspace unavailable (%d x %d floats)", gx + tiles_n, N);
+    a.stat_sum = dp.buf(0); a.stat_sq = dp.buf(1); a.stat_slots = gx + tiles_n; a.stat_stride = N;
+  }
 #define SY11_P1(TT, BNN, WMM, WNN, EE)                                                                                           \
   do {                                                                                                                            \
     if (lds > 64 * 1024)                                                                                                          \
@@ -257,5 +266,9 @@ int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, floa
 #undef SY11_P1E
 #undef SY11_P1
   SY11_LAUNCH_CHECK("igemm1x1p");
+  if (det) {
+    const int rc = dp.fold(0, stat_sum);
+    return rc ? rc : dp.fold(1, stat_sq);
+  }
   return SY11_OK;
 }

@@ -11,6 +11,7 @@
 //   K4 tal_norm    per anchor: normalised alignment score (= sum of its target_scores) and its global sum
 //   K5 loss_grad   per anchor: loss terms (forward) or d loss / d logits (backward; upstream scalar read from device memory)
 #include "common.h"
+#include "det.h"
 
 #define REG 16
 #define TOPK 10
@@ -30,8 +31,10 @@ struct LossArgs {
   float* pos_align;     // (B, G)
   float* pos_ov;        // (B, G)
   float* norm;          // (B, A)
-  float* sums;          // (64 slots, 4): tss, box, cls, dfl
+  float* sums;          // (sum_slots, 4): tss, box, cls, dfl
+  int sum_slots;        // 64 (the caller's buffer) or, ordered mode, one row per workgroup of the stream's workspace (det.h)
   const float* gscale;  // backward: upstream gradient (device scalar)
+  const float* gscale2; // backward: optional second device factor (1 / max(tss, 1) from loss_finish), or NULL
   float gain_box, gain_cls, gain_dfl;
 };
 
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void loss_tal_norm_kernel(const LossArgs a) {
   for (int o = 32; o >= 1; o >>= 1) nv += __shfl_xor(nv, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(a.sums + (blockIdx.x & 63) * 4, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) atomicAdd(a.sums + (long)(blockIdx.x % a.sum_slots) * 4, ((red[0] + red[1]) + red[2]) + red[3]);
 }
 
 // ---- K5: loss terms (BWD = false) or gradient w.r.t. the logits (BWD = true)
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float
     const int asg = a.assign[gi];
     const float w = a.norm[gi];                                  // = sum_c target_scores
     float up = 1.f;
-    if (BWD) up = a.gscale[0] * (float)a.B * tss_inv;            // d(total)/d(term sum): loss = B * sum(gain_i * term_i / tss)
+    if (BWD) up = a.gscale[0] * (a.gscale2 ? a.gscale2[0] : 1.f) * (float)a.B * tss_inv;            // d(total)/d(term sum): loss = B * sum(gain_i * term_i / tss)
     int label = -1;
     float tx1 = 0, ty1 = 0, tx2 = 0, ty2 = 0;
     const float st = a.strides[l];
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float
     if (threadIdx.x < 3) {
       float s = 0.f;
       for (int q = 0; q < 16; ++q) s += red[threadIdx.x][q];
-      atomicAdd(a.sums + (blockIdx.x & 63) * 4 + 1 + threadIdx.x, s);
+      atomicAdd(a.sums + (long)(blockIdx.x % a.sum_slots) * 4 + 1 + threadIdx.x, s);
     }
   }
 }
@@ -367,7 +370,7 @@ static int fill_args(LossArgs& a, int B, int nc, int nl, const float* const* map
   SY11_REQUIRE((long)B * A < (1L << 31), "det_loss: too many anchors");
   a.B = B; a.nc = nc; a.nl = nl; a.A = A; a.G = G; a.no = 4 * REG + nc;
   a.gt = gt; a.pbox = pbox; a.align = align; a.overlap = overlap; a.topk = topk; a.assign = assign;
-  a.pos_align = pos; a.pos_ov = pos ? pos + (long)B * G : nullptr; a.norm = norm; a.sums = sums;
+  a.pos_align = pos; a.pos_ov = pos ? pos + (long)B * G : nullptr; a.norm = norm; a.sums = sums; a.sum_slots = 64;
   return SY11_OK;
 }
 
@@ -390,9 +393,15 @@ extern "C" int sy11_det_loss_assign(int32_t B, int32_t nc, int32_t nl, const flo
     hipLaunchKernelGGL(loss_tal_metrics_kernel, dim3(G, B), dim3(256), lds, st, a);
   }
   hipLaunchKernelGGL(loss_tal_resolve_kernel, dim3((unsigned)((BA + 255) / 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(loss_tal_norm_kernel, dim3((unsigned)((BA + 255) / 256)), dim3(256), 0, st, a);
+  DetPartials dp;                                   // ordered mode: the tss partials as one row per workgroup, folded in index order
+  const long nb = (BA + 255) / 256;
+  if (sy11_det(16)) {
+    if (!dp.acquire(st, 1, nb, 4)) SY11_FAIL(SY11_ELAUNCH, "det_loss_assign: ordered-reduction workspace unavailable");
+    a.sums = dp.buf(0); a.sum_slots = (int)nb;
+  }
+  hipLaunchKernelGGL(loss_tal_norm_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
   SY11_LAUNCH_CHECK("det_loss_assign");
-  return SY11_OK;
+  return dp.base ? dp.fold(0, sums) : SY11_OK;
 }
 
 // terms: sums[.][1..3] += box / cls / dfl partial sums (un-normalised: divide by max(tss,1) on the device afterwards)
@@ -405,17 +414,23 @@ extern "C" int sy11_det_loss_terms(int32_t B, int32_t nc, int32_t nl, const floa
                      (float*)norm, sums);
   if (rc) return rc;
   const long BA = (long)B * a.A;
-  hipLaunchKernelGGL((loss_terms_kernel<false>), dim3((unsigned)((BA + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a, 1.f);
+  DetPartials dp;
+  const long nb = (BA + 15) / 16;
+  if (sy11_det(16)) {
+    if (!dp.acquire((hipStream_t)stream, 1, nb, 4)) SY11_FAIL(SY11_ELAUNCH, "det_loss_terms: ordered-reduction workspace unavailable");
+    a.sums = dp.buf(0); a.sum_slots = (int)nb;
+  }
+  hipLaunchKernelGGL((loss_terms_kernel<false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a, 1.f);
   SY11_LAUNCH_CHECK("det_loss_terms");
-  return SY11_OK;
+  return dp.base ? dp.fold(0, sums) : SY11_OK;
 }
 
 // backward: dmaps[l] = d(loss)/d(maps[l]) where loss = B * (gain_box*box + gain_cls*cls + gain_dfl*dfl) / tss, times *gscale.
 // tss_inv_dev: device scalar 1/max(tss,1) is folded on the host side into `tss_inv` via a tiny device op -> passed by pointer.
 extern "C" int sy11_det_loss_bwd(int32_t B, int32_t nc, int32_t nl, const float* const* maps, float* const* dmaps, const int32_t* hs,
                                  const int32_t* ws, const float* strides, int32_t G, const float* gt, const int32_t* assign,
-                                 const float* norm, const float* gscale_times_tssinv, float gain_box, float gain_cls, float gain_dfl,
-                                 void* stream) {
+                                 const float* norm, const float* gscale_times_tssinv, const float* second_factor, float gain_box, float gain_cls,
+                                 float gain_dfl, void* stream) {
   LossArgs a{};
   static float dummy;
   SY11_REQUIRE(dmaps && gscale_times_tssinv, "det_loss_bwd: null pointer");
@@ -423,9 +438,80 @@ extern "C" int sy11_det_loss_bwd(int32_t B, int32_t nc, int32_t nl, const float*
                      (float*)norm, &dummy);
   if (rc) return rc;
   a.gscale = gscale_times_tssinv;
+  a.gscale2 = second_factor;
   a.gain_box = gain_box; a.gain_cls = gain_cls; a.gain_dfl = gain_dfl;
   const long BA = (long)B * a.A;
   hipLaunchKernelGGL((loss_terms_kernel<true>), dim3((unsigned)((BA + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a, 1.f);
   SY11_LAUNCH_CHECK("det_loss_bwd");
+  return SY11_OK;
+}
+
+
+// ---- target packing (v8DetectionLoss.preprocess, utils/loss.py:194-207): the (n) targets [image, cls, xywh normalised] of a batch ->
+// gt (B, G, 5) rows [cls, x1, y1, x2, y2] in pixels, an image's targets in their original order, zero rows as padding.  One wave
+// per image: a ballot over 64 targets at a time gives every match its rank.  Replaces ~12 ATen launches (cat, bincount / scatter,
+// argsort, cumsum, index_put, the xywh2xyxy slices) and the per-image host loop of the reference.
+__global__ __launch_bounds__(64) void loss_pack_targets_kernel(int n, int G, const float* __restrict__ idx, int idx_st, const float* __restrict__ cls,
+                                                               int cls_st, const float* __restrict__ box, int box_st, float sw, float sh,
+                                                               float* __restrict__ gt) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float* out = gt + (long)b * G * 5;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    const bool hit = i < n && (int)idx[(long)i * idx_st] == b;
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int r = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (r < G) {
+        const float* bx = box + (long)i * box_st;
+        // out[..., 1:5] * scale, then xywh2xyxy.  Every product goes through an empty asm so the backend cannot fuse it into the
+        // following add / subtract (-ffp-contract=fast fuses at instruction selection): bit-exact against the tensor-op order
+        float cx = bx[0] * sw, cy = bx[1] * sh, hw = bx[2] * sw, hh = bx[3] * sh;
+        asm volatile("" : "+v"(cx), "+v"(cy), "+v"(hw), "+v"(hh));
+        hw *= 0.5f; hh *= 0.5f;
+        float* o = out + (long)r * 5;
+        o[0] = cls[(long)i * cls_st];
+        o[1] = cx - hw; o[2] = cy - hh; o[3] = cx + hw; o[4] = cy + hh;
+      }
+    }
+    base += __popcll(m);
+  }
+  for (int r = (base < G ? base : G) + lane; r < G; r += 64) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) out[(long)r * 5 + q] = 0.f;
+  }
+}
+
+extern "C" int sy11_det_loss_pack_targets(int32_t n, int32_t B, int32_t G, const float* batch_idx, int32_t idx_stride, const float* cls,
+                                          int32_t cls_stride, const float* bboxes, int32_t box_stride, float scale_w, float scale_h, float* gt,
+                                          void* stream) {
+  SY11_REQUIRE(n >= 0 && B > 0 && G >= 0 && gt, "det_loss_pack_targets: bad argument");
+  SY11_REQUIRE(n == 0 || (batch_idx && cls && bboxes && idx_stride >= 1 && cls_stride >= 1 && box_stride >= 4), "det_loss_pack_targets: null / short-stride target columns");
+  if (G == 0) return SY11_OK;
+  hipLaunchKernelGGL(loss_pack_targets_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, n, G, batch_idx, idx_stride, cls, cls_stride, bboxes, box_stride, scale_w,
+                     scale_h, gt);
+  SY11_LAUNCH_CHECK("det_loss_pack_targets");
+  return SY11_OK;
+}
+
+// ---- finish: sums (64, 4) partials -> out[0] = loss = B * sum_i gain_i * term_i / max(tss, 1), out[1..3] = the three gained items,
+// out[4] = 1 / max(tss, 1) (the backward launch multiplies the upstream gradient by it).  The 64 slots are folded in index order.
+__global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict__ sums, int B, float gb, float gc, float gd, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < 64; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] += sums[s * 4 + q];
+  const float tss = fmaxf(t[0], 1.f);
+  const float i0 = t[1] / tss * gb, i1 = t[2] / tss * gc, i2 = t[3] / tss * gd;
+  out[1] = i0; out[2] = i1; out[3] = i2;
+  out[0] = ((i0 + i1) + i2) * (float)B;
+  out[4] = 1.f / tss;
+}
+extern "C" int sy11_det_loss_finish(const float* sums, int32_t B, float gain_box, float gain_cls, float gain_dfl, float* out, void* stream) {
+  SY11_REQUIRE(sums && out && B > 0, "det_loss_finish: bad argument");
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, gain_box, gain_cls, gain_dfl, out);
+  SY11_LAUNCH_CHECK("det_loss_finish");
   return SY11_OK;
 }

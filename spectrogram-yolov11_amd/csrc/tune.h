@@ -16,7 +16,7 @@
 
 // process-wide options (core.hip): defaults come from the environment (SY11_TUNE, SY11_TUNE_LOG, SY11_IGEMM_CFG,
 // SY11_WGRAD_CFG, SY11_IGEMM_KORDER, SY11_IGEMM_DEEP, SY11_IGEMM_BPOL), sy11_set_option() changes them at run time
-enum Sy11Opt { OPT_TUNE = 0, OPT_TUNE_LOG, OPT_IGEMM_CFG, OPT_WGRAD_CFG, OPT_IGEMM_KORDER, OPT_IGEMM_DEEP, OPT_IGEMM_BPOL, OPT_DGRAD_S2_HALO, OPT_ROW_MAP, OPT_COUNT };
+enum Sy11Opt { OPT_TUNE = 0, OPT_TUNE_LOG, OPT_IGEMM_CFG, OPT_WGRAD_CFG, OPT_IGEMM_KORDER, OPT_IGEMM_DEEP, OPT_IGEMM_BPOL, OPT_DGRAD_S2_HALO, OPT_ROW_MAP, OPT_DETERMINISTIC, OPT_COUNT };
 int sy11_opt(int which);
 
 namespace sy11tune {

@@ -11,6 +11,7 @@
 // cover 128 contiguous bytes.
 #include "common.h"
 #include "tune.h"
+#include "det.h"
 #include <stdlib.h>
 
 struct WgradArgs {
@@ -25,6 +26,7 @@ struct WgradArgs {
   unsigned mag_ow, mag_oh;      // ceil(2^20 / OW), ceil(2^20 / OH): exact quotients for the small ranges of the pixel walk
   int tiles, total;      // tiles per pixel split, tiles * splits
   int pix_per_split;     // multiple of BP
+  long dw_split_stride;  // 0: every pixel split adds into the one dW (atomics); ordered mode: split s owns dw + s * stride (det.h)
   signed char tap_dy[64];
   signed char tap_dx[64];
 };
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int n0 = tile_n * TILE, k0 = tile_k * TILE;
   const int m_begin = split * a.pix_per_split;
   const int m_end = min(a.M, m_begin + a.pix_per_split);
+  float* const dwp = a.dw + (long)split * a.dw_split_stride;
   if (m_begin >= m_end) return;
 
   const int chunk = tid % CPR, prow = tid / CPR;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wr * (TILE / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         const int k = k0 + wc * (TILE / 2) + j * 32 + fcol;
-        if (n < a.N && k < a.K) atomicAdd(a.dw + (long)n * a.K + k, acc[i][j][e]);
+        if (n < a.N && k < a.K) atomicAdd(dwp + (long)n * a.K + k, acc[i][j][e]);
       }
 }
 
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
   const int n0 = tile_n * TILE, k0 = tile_k * TILE;
   const int m_begin = split * a.pix_per_split;
   const int m_end = min(a.M, m_begin + a.pix_per_split);
+  float* const dwp = a.dw + (long)split * a.dw_split_stride;
   if (m_begin >= m_end) return;
 
   const int chunk = tid % CPR, prow = tid / CPR;
@@ -353,12 +357,12 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
     for (int e = 0; e < 16; ++e) {
       const int n = n0 + fi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
       const int k = k0 + fj * 32 + fcol;
-      if (n < a.N && k < a.K) atomicAdd(a.dw + (long)n * a.K + k, tot[e]);
+      if (n < a.N && k < a.K) atomicAdd(dwp + (long)n * a.K + k, tot[e]);
     }
     return;
   }
   if (n0 + TILE <= a.N && k0 + TILE <= a.K) {            // interior tile (the common case): no per-element bounds branches
-    float* base = a.dw + (long)(n0 + wr * (TILE / 2) + 4 * fh) * a.K + k0 + wc * (TILE / 2) + fcol;
+    float* base = dwp + (long)(n0 + wr * (TILE / 2) + 4 * fh) * a.K + k0 + wc * (TILE / 2) + fcol;
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wr * (TILE / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         const int k = k0 + wc * (TILE / 2) + j * 32 + fcol;
-        if (n < a.N && k < a.K) atomicAdd(a.dw + (long)n * a.K + k, acc[i][j][e]);
+        if (n < a.N && k < a.K) atomicAdd(dwp + (long)n * a.K + k, acc[i][j][e]);
       }
 }
 
@@ -411,6 +415,16 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   a.pix_per_split = cdiv(cdiv(a.M, splits), 64) * 64;
   splits = cdiv(a.M, a.pix_per_split);
   a.tiles = tiles; a.total = tiles * splits;
+  // ordered mode: one partial dW per pixel split, folded in split order afterwards (a single split adds straight into dW: one
+  // add per element onto whatever the accumulation window already holds — exact)
+  DetPartials dp;
+  float* const dw_out = a.dw;
+  const bool det = sy11_det(8) && splits > 1;
+  if (det) {
+    if (!dp.acquire(st, 1, splits, a.N * a.K)) SY11_FAIL(SY11_ELAUNCH, "conv2d_wgrad: ordered-reduction workspace unavailable (%d x %d floats)", splits, a.N * a.K);
+    a.dw = dp.buf(0);
+    a.dw_split_stride = (long)a.N * a.K;
+  }
   a.mag_ow = (unsigned)(((1u << 20) + a.OW - 1) / a.OW);
   a.mag_oh = (unsigned)(((1u << 20) + a.OH - 1) / a.OH);
   dim3 grid(cdiv(a.total, 8) * 8), block(256);
@@ -427,6 +441,7 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
     else hipLaunchKernelGGL((wgrad16_kernel<__bf16, 64>), grid, block, 0, st, a);
   }
   SY11_LAUNCH_CHECK("conv2d_wgrad");
+  if (det) return dp.fold(0, dw_out);
   return SY11_OK;
 }
 

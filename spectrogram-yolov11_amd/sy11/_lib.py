@@ -32,9 +32,18 @@ class BnTail(C.Structure):
         + [("eps", C.c_float), ("momentum", C.c_float), ("count", C.c_double)]
 
 
+class OptDesc(C.Structure):
+    """sy11_opt_desc: one optimizer step over the flat buffers (include/sy11.h)."""
+    _fields_ = [("n", C.c_int64), ("n_buf", C.c_int64), ("group_end", C.c_int64 * 3), ("lr", C.c_float * 3), ("momentum", C.c_float * 3),
+                ("weight_decay", C.c_float * 3), ("kind", C.c_int32), ("beta2", C.c_float), ("eps", C.c_float), ("max_norm", C.c_float),
+                ("ema_decay", C.c_float), ("amp", C.c_int32), ("growth_factor", C.c_float), ("backoff_factor", C.c_float),
+                ("growth_interval", C.c_int32), ("nparts", C.c_int32)]
+
+
 _vp, _i32, _i64, _f32, _f64, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32
 _dp = C.POINTER(ConvDesc)
 _bp = C.POINTER(BnTail)
+_op = C.POINTER(OptDesc)
 
 # name -> argtypes (restype is int unless noted); the single source the symbol-export test checks against sy11.h
 SIGNATURES = {
@@ -67,13 +76,16 @@ SIGNATURES = {
     "sy11_maxpool5_fwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp],
     "sy11_maxpool5_bwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp],
     "sy11_cast": [_i32, _i32, _i64, _vp, _vp, _vp],
+    "sy11_bias_grad_cast": [_i32, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
     "sy11_attention_fwd": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp],
     "sy11_attention_bwd": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
     "sy11_detect_decode": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_nms_sorted": [_i32, _vp, _f32, _vp, _vp, _vp],
     "sy11_det_loss_assign": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_det_loss_terms": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
-    "sy11_det_loss_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp],
+    "sy11_det_loss_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp],
+    "sy11_det_loss_pack_targets": [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _f32, _f32, _vp, _vp],
+    "sy11_det_loss_finish": [_vp, _i32, _f32, _f32, _f32, _vp, _vp],
     "sy11_stft_logmel": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "sy11_stft_minmax_init": [_i32, _vp, _vp],
     "sy11_stft_normalize": [_i32, _i32, _i32, _vp, _vp, _vp, _vp],
@@ -88,6 +100,9 @@ SIGNATURES.update({
     "sy11_tune_import": [_vp, _i64],
     "sy11_tune_clear": [],
     "sy11_peak_mfma_f16": [_i32, _i32, _vp, _vp],
+    "sy11_opt_workspace_floats": [_i32],
+    "sy11_opt_grad_norm": [_i64, _vp, _vp, _vp, _vp, _i32, _vp],
+    "sy11_opt_step": [_op, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 })
 OTHER = {"sy11_version": ([], C.c_int), "sy11_last_error": ([], C.c_char_p),
          "sy11_nms_workspace_bytes": ([_i32], C.c_size_t),

@@ -353,225 +353,240 @@ def get_rotation_matrix_2d(center, angle, scale):
 
 
 # ------------------------------------------------------------------------------------------------ training transforms
+# The host side of the training pipeline is a RECIPE GENERATOR: each transform draws its random numbers (in the reference's order,
+# from the reference's two generators — `random` and `np.random` — so that a seeded run consumes the same streams), turns them into
+# geometry (tile rectangles, one 3x3 matrix, three 256-entry tables, two flip bits) recorded on the DeviceImage, and moves the few
+# boxes of the sample through that geometry in float32.  No pixel is touched here; sy11_image_mosaic_warp renders the recipe.
+def mosaic_quadrant(i, xc, yc, w, h, side):
+    """Tile ``i`` (bit 0: right column, bit 1: bottom row) of a 2x2 mosaic on a ``side`` x ``side`` canvas whose four tiles meet at
+    (xc, yc): the tile's bottom-right / bottom-left / ... corner is pinned to the centre and whatever sticks out of the canvas is
+    cropped.  -> ((x1, y1, x2, y2) on the canvas, (padw, padh) = canvas position of the tile's own origin)."""
+    right, bottom = i & 1, i >> 1
+    x1, x2 = (xc, min(xc + w, side)) if right else (max(xc - w, 0), xc)
+    y1, y2 = (yc, min(yc + h, side)) if bottom else (max(yc - h, 0), yc)
+    crop_x = 0 if right else w - (x2 - x1)          # first source column / row that lands on the canvas
+    crop_y = 0 if bottom else h - (y2 - y1)
+    return (x1, y1, x2, y2), (x1 - crop_x, y1 - crop_y)
+
+
 class Mosaic:
-    """augment.py:495-870 (BaseMixTransform.__call__ :352-407 + Mosaic), the 2x2 grid: same draws in the same order
-    (apply coin, three buffer picks, the centre), same tile rectangles and label shifts.  The 2s x 2s canvas is never
-    allocated — the result is a four-tile DeviceImage."""
+    """augment.py:495-870 (BaseMixTransform.__call__ :352-407 + Mosaic), the 2x2 grid: same draws in the same order (apply coin,
+    three buffer picks, the centre), same tile rectangles and label shifts.  The 2s x 2s canvas is never allocated — the result
+    is a four-tile DeviceImage."""
 
     def __init__(self, dataset, imgsz=640, p=1.0, n=4):
-        assert 0 <= p <= 1.0, f"The probability should be in range [0, 1], but got {p}."
+        if not 0 <= p <= 1.0:
+            raise AssertionError(f"The probability should be in range [0, 1], but got {p}.")
         if n != 4:
             raise NotImplementedError("sy11 Mosaic implements the 2x2 grid (n=4) the v8 pipeline uses")
-        self.dataset = dataset
+        self.dataset, self.imgsz, self.p, self.n = dataset, imgsz, p, n
         self.pre_transform = None
-        self.p = p
-        self.imgsz = imgsz
         self.border = (-imgsz // 2, -imgsz // 2)
-        self.n = n
 
     def get_indexes(self, buffer=True):
+        """The three partner samples: from the dataset's recent-sample buffer (default) or from the whole dataset."""
+        k = self.n - 1
         if buffer:
-            return random.choices(list(self.dataset.buffer), k=self.n - 1)
-        return [random.randint(0, len(self.dataset) - 1) for _ in range(self.n - 1)]
+            return random.choices(list(self.dataset.buffer), k=k)
+        return [random.randint(0, len(self.dataset) - 1) for _ in range(k)]
 
     def __call__(self, labels):
-        if random.uniform(0, 1) > self.p:
+        if random.uniform(0, 1) > self.p:                          # draw 1: apply at all?
             return labels
-        indexes = self.get_indexes()
-        mix_labels = [self.dataset.get_image_and_label(i) for i in indexes]
+        partners = [self.dataset.get_image_and_label(i) for i in self.get_indexes()]        # draws 2-4
         if self.pre_transform is not None:
-            mix_labels = [self.pre_transform(d) for d in mix_labels]
-        labels["mix_labels"] = mix_labels
-        labels = self._mosaic4(labels)
-        labels.pop("mix_labels", None)
-        return labels
+            partners = [self.pre_transform(d) for d in partners]
+        return self._compose([labels] + partners)
 
     def _mosaic4(self, labels):
-        mosaic_labels = []
-        s = self.imgsz
-        yc, xc = (int(random.uniform(-x, 2 * s + x)) for x in self.border)
-        tiles = []
-        was_numpy = False
-        for i in range(4):
-            patch = labels if i == 0 else labels["mix_labels"][i - 1]
-            di = DeviceImage.wrap(patch["img"])
-            was_numpy |= di.was_numpy
-            h, w = patch.pop("resized_shape")
-            if i == 0:      # top left
-                x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
-                x1b, y1b, x2b, y2b = w - (x2a - x1a), h - (y2a - y1a), w, h
-            elif i == 1:    # top right
-                x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, s * 2), yc
-                x1b, y1b, x2b, y2b = 0, h - (y2a - y1a), min(w, x2a - x1a), h
-            elif i == 2:    # bottom left
-                x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(s * 2, yc + h)
-                x1b, y1b, x2b, y2b = w - (x2a - x1a), 0, w, min(y2a - y1a, h)
-            else:           # bottom right
-                x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s * 2), min(s * 2, yc + h)
-                x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
-            padw, padh = x1a - x1b, y1a - y1b
-            if x2a > x1a and y2a > y1a:
-                tiles.append((di.render(chw=False), x1a, y1a, x2a, y2a, padw, padh))
-            patch = self._update_labels(patch, padw, padh, di.shape[:2])
-            mosaic_labels.append(patch)
-        final = self._cat_labels(mosaic_labels)
-        canvas = DeviceImage(tiles, (2 * s, 2 * s))
-        canvas.was_numpy = was_numpy
-        final["img"] = canvas.unwrap()
-        return final
+        """Reference entry point (labels carrying "mix_labels"); the work is _compose's."""
+        return self._compose([labels] + list(labels.pop("mix_labels")))
+
+    def _compose(self, samples):
+        side = 2 * self.imgsz
+        yc, xc = (int(random.uniform(-b, side + b)) for b in self.border)      # draws 5, 6: centre row, then centre column
+        tiles, placed, from_numpy = [], [], False
+        for i, sample in enumerate(samples):
+            image = DeviceImage.wrap(sample["img"])
+            from_numpy |= image.was_numpy
+            h, w = sample.pop("resized_shape")
+            rect, (padw, padh) = mosaic_quadrant(i, xc, yc, w, h, side)
+            if rect[2] > rect[0] and rect[3] > rect[1]:             # a tile pushed entirely off the canvas contributes no pixels
+                tiles.append((image.render(chw=False), *rect, padw, padh))
+            placed.append(self._update_labels(sample, padw, padh, image.shape[:2]))
+        canvas = DeviceImage(tiles, (side, side))
+        canvas.was_numpy = from_numpy
+        out = self._cat_labels(placed)
+        out["img"] = canvas.unwrap()
+        return out
 
     @staticmethod
     def _update_labels(labels, padw, padh, hw=None):
-        nh, nw = hw if hw is not None else labels["img"].shape[:2]
-        labels["instances"].convert_bbox(format="xyxy")
-        labels["instances"].denormalize(nw, nh)
-        labels["instances"].add_padding(padw, padh)
+        """A tile's boxes in canvas pixels: corner format, de-normalised by the tile's size, shifted by its canvas position."""
+        th, tw = hw if hw is not None else labels["img"].shape[:2]
+        inst = labels["instances"]
+        inst.convert_bbox(format="xyxy")
+        inst.denormalize(tw, th)
+        inst.add_padding(padw, padh)
         return labels
 
     def _cat_labels(self, mosaic_labels):
-        if len(mosaic_labels) == 0:
+        """Boxes of all tiles together, clipped to the canvas; boxes clipped to nothing are dropped with their classes."""
+        if not mosaic_labels:
             return {}
-        imgsz = self.imgsz * 2
-        final = {
-            "im_file": mosaic_labels[0].get("im_file"),
-            "ori_shape": mosaic_labels[0].get("ori_shape"),
-            "resized_shape": (imgsz, imgsz),
-            "cls": np.concatenate([l["cls"] for l in mosaic_labels], 0),
-            "instances": Instances.concatenate([l["instances"] for l in mosaic_labels], axis=0),
-            "mosaic_border": self.border,
-        }
-        final["instances"].clip(imgsz, imgsz)
-        good = final["instances"].remove_zero_area_boxes()
-        final["cls"] = final["cls"][good]
-        return final
+        side = 2 * self.imgsz
+        first = mosaic_labels[0]
+        inst = Instances.concatenate([d["instances"] for d in mosaic_labels], axis=0)
+        inst.clip(side, side)
+        alive = inst.remove_zero_area_boxes()
+        return {"im_file": first.get("im_file"), "ori_shape": first.get("ori_shape"), "resized_shape": (side, side),
+                "cls": np.concatenate([d["cls"] for d in mosaic_labels], 0)[alive], "instances": inst, "mosaic_border": self.border}
+
+
+def _mat3(**entries):
+    """float32 identity with the given entries, keyed 'rc' (row, column), e.g. _mat3(**{'02': tx})."""
+    m = np.eye(3, dtype=np.float32)
+    for key, v in entries.items():
+        m[int(key[0]), int(key[1])] = v
+    return m
+
+
+def draw_affine(in_hw, out_wh, degrees, translate, scale, shear, perspective=0.0):
+    """The eight draws of RandomPerspective.affine_transform in the reference's order (two perspective terms — drawn even though
+    they are zero here —, angle, zoom, two shears, two translations) -> (M = T @ S @ R @ P @ C as float32 3x3, zoom).
+    C centres the input, R rotates / zooms about the origin, S shears, T moves the origin to a jittered centre of the output."""
+    h, w = in_hw
+    C = _mat3(**{"02": -w / 2, "12": -h / 2})
+    P = _mat3(**{"20": random.uniform(-perspective, perspective), "21": random.uniform(-perspective, perspective)})
+    angle = random.uniform(-degrees, degrees)
+    zoom = random.uniform(1 - scale, 1 + scale)
+    R = _mat3()
+    R[:2] = get_rotation_matrix_2d(center=(0, 0), angle=angle, scale=zoom)
+    S = _mat3(**{"01": math.tan(random.uniform(-shear, shear) * math.pi / 180), "10": math.tan(random.uniform(-shear, shear) * math.pi / 180)})
+    T = _mat3(**{"02": random.uniform(0.5 - translate, 0.5 + translate) * out_wh[0],
+                 "12": random.uniform(0.5 - translate, 0.5 + translate) * out_wh[1]})
+    M = T
+    for nxt in (S, R, P, C):                                       # left to right, each product rounded to float32
+        M = M @ nxt
+    return M, zoom
+
+
+def warp_boxes(bboxes, M):
+    """xyxy boxes through the affine map ``M``: the axis-aligned hull of the four mapped corners (float32 throughout)."""
+    n = len(bboxes)
+    if n == 0:
+        return bboxes
+    corners = np.ones((n, 4, 3), dtype=bboxes.dtype)               # (x1,y1) (x2,y2) (x1,y2) (x2,y1), homogeneous
+    corners[:, 0, :2] = bboxes[:, [0, 1]]
+    corners[:, 1, :2] = bboxes[:, [2, 3]]
+    corners[:, 2, :2] = bboxes[:, [0, 3]]
+    corners[:, 3, :2] = bboxes[:, [2, 1]]
+    mapped = (corners.reshape(4 * n, 3) @ M.T)[:, :2].reshape(n, 4, 2)
+    return np.concatenate((mapped.min(1), mapped.max(1)), 1, dtype=bboxes.dtype)
+
+
+def surviving_boxes(before, after, wh_thr=2, ar_thr=100, area_thr=0.1, eps=1e-16):
+    """Which warped boxes are still usable: more than ``wh_thr`` pixels wide and high, at least ``area_thr`` of the (zoomed)
+    original area left after clipping, aspect ratio below ``ar_thr``.  ``before`` / ``after``: (n, 4) xyxy."""
+    w0, h0 = before[:, 2] - before[:, 0], before[:, 3] - before[:, 1]
+    w1, h1 = after[:, 2] - after[:, 0], after[:, 3] - after[:, 1]
+    aspect = np.maximum(w1 / (h1 + eps), h1 / (w1 + eps))
+    big_enough = (w1 > wh_thr) & (h1 > wh_thr)
+    return big_enough & (w1 * h1 / (w0 * h0 + eps) > area_thr) & (aspect < ar_thr)
 
 
 class RandomPerspective:
-    """augment.py:873-1300 for the affine case the detection pipeline uses (perspective = 0): the eight draws in the
-    reference's order, M = T @ S @ R @ P @ C in float32, boxes through the four corners, the box_candidates filter.
-    The warp itself is recorded on the DeviceImage (executed by the fused render)."""
+    """augment.py:873-1300 for the affine case the detection pipeline uses (perspective = 0).  ``__call__`` = draw_affine + one
+    recorded warp on the DeviceImage (executed by the fused render) + warp_boxes + surviving_boxes."""
 
     def __init__(self, degrees=0.0, translate=0.1, scale=0.5, shear=0.0, perspective=0.0, border=(0, 0), pre_transform=None):
         if perspective:
             raise NotImplementedError("sy11 RandomPerspective implements the affine case (perspective=0.0, the default)")
-        self.degrees = degrees
-        self.translate = translate
-        self.scale = scale
-        self.shear = shear
-        self.perspective = perspective
+        self.degrees, self.translate, self.scale, self.shear, self.perspective = degrees, translate, scale, shear, perspective
         self.border = border
         self.pre_transform = pre_transform
 
+    # the reference's method names, for callers that use the pieces
     def affine_transform(self, img, border):
-        C = np.eye(3, dtype=np.float32)
-        C[0, 2] = -img.shape[1] / 2
-        C[1, 2] = -img.shape[0] / 2
-        P = np.eye(3, dtype=np.float32)
-        P[2, 0] = random.uniform(-self.perspective, self.perspective)
-        P[2, 1] = random.uniform(-self.perspective, self.perspective)
-        R = np.eye(3, dtype=np.float32)
-        a = random.uniform(-self.degrees, self.degrees)
-        s = random.uniform(1 - self.scale, 1 + self.scale)
-        R[:2] = get_rotation_matrix_2d(angle=a, center=(0, 0), scale=s)
-        S = np.eye(3, dtype=np.float32)
-        S[0, 1] = math.tan(random.uniform(-self.shear, self.shear) * math.pi / 180)
-        S[1, 0] = math.tan(random.uniform(-self.shear, self.shear) * math.pi / 180)
-        T = np.eye(3, dtype=np.float32)
-        T[0, 2] = random.uniform(0.5 - self.translate, 0.5 + self.translate) * self.size[0]
-        T[1, 2] = random.uniform(0.5 - self.translate, 0.5 + self.translate) * self.size[1]
-        M = T @ S @ R @ P @ C
-        if (border[0] != 0) or (border[1] != 0) or (M != np.eye(3)).any():
+        M, zoom = draw_affine(img.shape[:2], self.size, self.degrees, self.translate, self.scale, self.shear, self.perspective)
+        if any(border) or (M != np.eye(3)).any():                  # the identity on an un-bordered image is skipped, as there
             img = DeviceImage.wrap(img).warp(M[:2], dsize=self.size).unwrap()
-        return img, M, s
+        return img, M, zoom
 
-    def apply_bboxes(self, bboxes, M):
-        n = len(bboxes)
-        if n == 0:
-            return bboxes
-        xy = np.ones((n * 4, 3), dtype=bboxes.dtype)
-        xy[:, :2] = bboxes[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)
-        xy = xy @ M.T
-        xy = xy[:, :2].reshape(n, 8)
-        x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
-        return np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1)), dtype=bboxes.dtype).reshape(4, n).T
-
-    def __call__(self, labels):
-        if self.pre_transform and "mosaic_border" not in labels:
-            labels = self.pre_transform(labels)
-        labels.pop("ratio_pad", None)
-        img = labels["img"]
-        cls = labels["cls"]
-        instances = labels.pop("instances")
-        instances.convert_bbox(format="xyxy")
-        instances.denormalize(*img.shape[:2][::-1])
-        border = labels.pop("mosaic_border", self.border)
-        self.size = img.shape[1] + border[1] * 2, img.shape[0] + border[0] * 2
-        img, M, scale = self.affine_transform(img, border)
-        bboxes = self.apply_bboxes(instances.bboxes, M)
-        new_instances = Instances(bboxes, bbox_format="xyxy", normalized=False)
-        new_instances.clip(*self.size)
-        instances.scale(scale_w=scale, scale_h=scale, bbox_only=True)
-        i = self.box_candidates(box1=instances.bboxes.T, box2=new_instances.bboxes.T, area_thr=0.10)
-        labels["instances"] = new_instances[i]
-        labels["cls"] = cls[i]
-        labels["img"] = img
-        labels["resized_shape"] = img.shape[:2]
-        return labels
+    apply_bboxes = staticmethod(warp_boxes)
 
     @staticmethod
     def box_candidates(box1, box2, wh_thr=2, ar_thr=100, area_thr=0.1, eps=1e-16):
-        w1, h1 = box1[2] - box1[0], box1[3] - box1[1]
-        w2, h2 = box2[2] - box2[0], box2[3] - box2[1]
-        ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
-        return (w2 > wh_thr) & (h2 > wh_thr) & (w2 * h2 / (w1 * h1 + eps) > area_thr) & (ar < ar_thr)
+        """Reference layout: boxes as (4, n)."""
+        return surviving_boxes(box1.T, box2.T, wh_thr, ar_thr, area_thr, eps)
+
+    def __call__(self, labels):
+        mosaic = "mosaic_border" in labels
+        if self.pre_transform and not mosaic:                      # a single image: letterbox it to the network size first
+            labels = self.pre_transform(labels)
+        labels.pop("ratio_pad", None)
+        img = labels["img"]
+        h, w = img.shape[:2]
+        border = labels.pop("mosaic_border", self.border)
+        self.size = (w + 2 * border[1], h + 2 * border[0])         # output (width, height): a mosaic canvas shrinks back to imgsz
+        src = labels.pop("instances")
+        src.convert_bbox(format="xyxy")
+        src.denormalize(w, h)
+        img, M, zoom = self.affine_transform(img, border)
+        moved = Instances(warp_boxes(src.bboxes, M), bbox_format="xyxy", normalized=False)
+        moved.clip(*self.size)
+        src.scale(scale_w=zoom, scale_h=zoom, bbox_only=True)      # the un-clipped size the box would have: reference for the area test
+        keep = surviving_boxes(src.bboxes, moved.bboxes, area_thr=0.10)
+        labels.update(instances=moved[keep], cls=labels["cls"][keep], img=img, resized_shape=img.shape[:2])
+        return labels
+
+
+def hsv_tables(gains):
+    """Three 256-entry uint8 tables for (hue, saturation, value) gains: hue wraps at 180 (OpenCV's 8-bit hue range), the other two
+    saturate at 255."""
+    ramp = np.arange(0, 256, dtype=gains.dtype)
+    return ((ramp * gains[0]) % 180).astype(np.uint8), np.clip(ramp * gains[1], 0, 255).astype(np.uint8), \
+        np.clip(ramp * gains[2], 0, 255).astype(np.uint8)
 
 
 class RandomHSV:
-    """augment.py:1303-1390 — the three gains from np.random.uniform, the three 256-entry tables built exactly as the
-    reference builds them; the colour conversions happen inside the fused render."""
+    """augment.py:1303-1390 — ONE np.random.uniform(-1, 1, 3) draw scaled by the three gain limits; the colour conversions happen
+    inside the fused render, from the tables recorded here."""
 
     def __init__(self, hgain=0.5, sgain=0.5, vgain=0.5):
-        self.hgain = hgain
-        self.sgain = sgain
-        self.vgain = vgain
+        self.hgain, self.sgain, self.vgain = hgain, sgain, vgain
 
     def __call__(self, labels):
-        img = labels["img"]
-        if self.hgain or self.sgain or self.vgain:
-            r = np.random.uniform(-1, 1, 3) * [self.hgain, self.sgain, self.vgain] + 1
-            x = np.arange(0, 256, dtype=r.dtype)
-            lut_hue = ((x * r[0]) % 180).astype(np.uint8)
-            lut_sat = np.clip(x * r[1], 0, 255).astype(np.uint8)
-            lut_val = np.clip(x * r[2], 0, 255).astype(np.uint8)
-            labels["img"] = DeviceImage.wrap(img).hsv((lut_hue, lut_sat, lut_val)).unwrap()
+        limits = [self.hgain, self.sgain, self.vgain]
+        if any(limits):
+            gains = np.random.uniform(-1, 1, 3) * limits + 1
+            labels["img"] = DeviceImage.wrap(labels["img"]).hsv(hsv_tables(gains)).unwrap()
         return labels
 
 
 class RandomFlip:
-    """augment.py:1393-1474 — one draw per instance (only the matching direction draws), boxes mirrored in xywh."""
+    """augment.py:1393-1474 — one `random.random()` draw per instance (only the configured direction draws), boxes mirrored in xywh."""
 
     def __init__(self, p=0.5, direction="horizontal", flip_idx=None):
-        assert direction in {"horizontal", "vertical"}, f"Support direction `horizontal` or `vertical`, got {direction}"
-        assert 0 <= p <= 1.0, f"The probability should be in range [0, 1], but got {p}."
-        self.p = p
-        self.direction = direction
-        self.flip_idx = flip_idx
+        if direction not in ("horizontal", "vertical"):
+            raise AssertionError(f"Support direction `horizontal` or `vertical`, got {direction}")
+        if not 0 <= p <= 1.0:
+            raise AssertionError(f"The probability should be in range [0, 1], but got {p}.")
+        self.p, self.direction, self.flip_idx = p, direction, flip_idx
 
     def __call__(self, labels):
-        img = labels["img"]
-        instances = labels.pop("instances")
-        instances.convert_bbox(format="xywh")
-        h, w = img.shape[:2]
-        h = 1 if instances.normalized else h
-        w = 1 if instances.normalized else w
-        if self.direction == "vertical" and random.random() < self.p:
-            img = DeviceImage.wrap(img).flip(ud=True).unwrap()
-            instances.flipud(h)
-        if self.direction == "horizontal" and random.random() < self.p:
-            img = DeviceImage.wrap(img).flip(lr=True).unwrap()
-            instances.fliplr(w)
-        labels["img"] = img
-        labels["instances"] = instances
+        inst = labels.pop("instances")
+        inst.convert_bbox(format="xywh")
+        if random.random() < self.p:
+            img = DeviceImage.wrap(labels["img"])
+            h, w = (1, 1) if inst.normalized else img.shape[:2]     # normalised boxes mirror about 1
+            if self.direction == "vertical":
+                inst.flipud(h)
+                labels["img"] = img.flip(ud=True).unwrap()
+            else:
+                inst.fliplr(w)
+                labels["img"] = img.flip(lr=True).unwrap()
+        labels["instances"] = inst
         return labels
 
 
@@ -591,12 +606,12 @@ def v8_transforms(dataset, imgsz, hyp, stretch=False):
     """augment.py:2270-2342 for detection defaults: Mosaic -> RandomPerspective (LetterBox pre-transform for the non-mosaic
     samples) -> [CopyPaste: no segments, no draw] -> MixUp(p=0: one draw) -> [Albumentations: not installed, no draw] ->
     RandomHSV -> RandomFlip(vertical) -> RandomFlip(horizontal)."""
-    mosaic = Mosaic(dataset, imgsz=imgsz, p=hyp.mosaic)
-    affine = RandomPerspective(degrees=hyp.degrees, translate=hyp.translate, scale=hyp.scale, shear=hyp.shear,
-                               perspective=hyp.perspective,
-                               pre_transform=None if stretch else LetterBox(new_shape=(imgsz, imgsz)))
     if getattr(hyp, "copy_paste", 0.0):
         raise NotImplementedError("copy_paste needs segment labels (out of scope for detection)")
-    return Compose([Compose([mosaic, affine]), _NoMix(getattr(hyp, "mixup", 0.0)),
-                    RandomHSV(hgain=hyp.hsv_h, sgain=hyp.hsv_s, vgain=hyp.hsv_v),
-                    RandomFlip(direction="vertical", p=hyp.flipud), RandomFlip(direction="horizontal", p=hyp.fliplr)])
+    geometry = Compose([Mosaic(dataset, imgsz=imgsz, p=hyp.mosaic),
+                        RandomPerspective(degrees=hyp.degrees, translate=hyp.translate, scale=hyp.scale, shear=hyp.shear,
+                                          perspective=hyp.perspective,
+                                          pre_transform=None if stretch else LetterBox(new_shape=(imgsz, imgsz)))])
+    colour = RandomHSV(hgain=hyp.hsv_h, sgain=hyp.hsv_s, vgain=hyp.hsv_v)
+    flips = [RandomFlip(direction=d, p=p) for d, p in (("vertical", hyp.flipud), ("horizontal", hyp.fliplr))]
+    return Compose([geometry, _NoMix(getattr(hyp, "mixup", 0.0)), colour, *flips])

@@ -67,6 +67,7 @@ class _StagedAllReduce:
         self.works = []
         self.stage0_done = False
         self.staging = None
+        self.timing = None            # a list: (start, end) event pairs on the launch stream around each stage's collectives (bench.py)
 
     def _ranges(self):
         """(late, early) lists of [start, end) element ranges of store.flat, merged over adjacent parameters."""
@@ -90,6 +91,15 @@ class _StagedAllReduce:
         self.late, self.early = late, early
 
     def __call__(self, s, stage):
+        if self.timing is None:
+            return self._run(s, stage)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._run(s, stage)
+        e1.record()
+        self.timing.append((e0, e1))
+
+    def _run(self, s, stage):
         if getattr(s, "defer_allreduce", False):
             return
         if stage == 0:

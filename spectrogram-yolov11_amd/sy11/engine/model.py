@@ -20,7 +20,7 @@ from ..nn.tasks import DetectionModel
 from .checkpoint import attempt_load_one_weight, save_checkpoint
 
 _TRAIN_KEYS = {"lr0", "momentum", "weight_decay", "nbs", "box", "cls", "dfl", "amp", "optimizer", "warmup_epochs", "warmup_momentum",
-               "warmup_bias_lr", "multi_scale", "imgsz"}
+               "warmup_bias_lr", "multi_scale", "imgsz", "deterministic"}
 
 
 def check_det_dataset(data):

@@ -15,7 +15,8 @@ from ..utils.torch_utils import ModelEMA
 from . import ddp
 
 DEFAULTS = dict(lr0=0.01, momentum=0.937, weight_decay=0.0005, nbs=64, box=7.5, cls=0.5, dfl=1.5, amp=True,
-                optimizer="SGD", warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, multi_scale=False, imgsz=640)
+                optimizer="SGD", warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, multi_scale=False, imgsz=640,
+                deterministic=None)      # None: leave libsy11's option as it is (SY11_DETERMINISTIC); True / False: cfg/default.yaml:29
 
 
 class DetectionTrainer:
@@ -31,6 +32,9 @@ class DetectionTrainer:
         self.world_size = world_size
         self.producer = producer                           # optional IQ -> image producer (SpectrogramProducer)
         self.amp = bool(self.args.amp)
+        if self.args.deterministic is not None and self.device.type == "cuda":
+            from ..utils.torch_utils import set_deterministic
+            set_deterministic(bool(self.args.deterministic))
         self.model._sy11_dtype = torch.float16 if self.amp else torch.float32
         for k, v in self.model.named_parameters():          # trainer.py:246-252: always freeze DFL
             if ".dfl" in k:
@@ -62,6 +66,7 @@ class DetectionTrainer:
             self.optimizer = self.build_flat_optimizer(self.flat_params, self.args.optimizer, self.args.lr0,
                                                        self.args.momentum, wd)
             self.ema = FlatEMA(self.model, self.flat)
+            self._hip_step_init()
         else:
             if world_size > 1:
                 ddp.broadcast_parameters(self.model)
@@ -135,6 +140,71 @@ class DetectionTrainer:
             for t in (b, w, n):
                 opt.state[t]["momentum_buffer"] = torch.zeros_like(t)
         return opt
+
+    # ---- optimizer step as two HIP launches (csrc/optim.hip)
+    _FLAT_TO_GROUP = (1, 2, 0)          # flat slices are [decay, norm, bias]; the torch optimizer's groups (the reference's order) [bias, decay, norm]
+
+    def _hip_step_init(self):
+        """On the MI355X the flat trainer steps through sy11_opt_grad_norm + sy11_opt_step; the torch optimizer object stays the
+        holder of the hyper-parameters (warm-up writes lr / momentum there) and of the STATE: its momentum buffers / Adam moments
+        become views of flat buffers this method owns, so state_dict() / checkpoints are unchanged."""
+        self._hip_step = self.flat is not None and self.device.type == "cuda" and type(self.optimizer).__name__ in ("SGD", "Adam", "AdamW")
+        if not self._hip_step:
+            return
+        from .. import ops as K
+        n = self.flat.flat.numel()
+        adam = type(self.optimizer).__name__ != "SGD"
+        self._opt_kind = 1 if adam else 0
+        self._opt_mom = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._opt_sq = torch.zeros(n, dtype=torch.float32, device=self.device) if adam else None
+        self._adam_step = torch.zeros((), dtype=torch.float32, device=self.device) if adam else None
+        self._opt_ws = K.opt_workspace(self.device)
+        if self.amp:
+            self.scaler._lazy_init_scale_growth_tracker(self.device)      # the two device scalars the step kernel updates in place
+        self._adopt_optimizer_state()
+
+    def _adopt_optimizer_state(self):
+        """(Re-)home the torch optimizer's state tensors into the flat momentum / moment buffers (after construction and after
+        load_state_dict, which replaces them with copies)."""
+        if not getattr(self, "_hip_step", False):
+            return
+        keys = ("exp_avg", "exp_avg_sq") if self._opt_kind else ("momentum_buffer",)
+        bufs = (self._opt_mom, self._opt_sq) if self._opt_kind else (self._opt_mom,)
+        for (a, b), t in zip(self.flat.group_slices, self.flat_params):
+            st = self.optimizer.state[t]
+            for key, flat in zip(keys, bufs):
+                view = flat[a:b]
+                old = st.get(key)
+                if old is not None and old.data_ptr() != view.data_ptr():
+                    view.copy_(old.to(view.device, torch.float32).reshape(-1))
+                st[key] = view
+            if self._opt_kind:
+                old = st.get("step")
+                if old is not None and old is not self._adam_step:
+                    self._adam_step.fill_(float(old))
+                st["step"] = self._adam_step
+
+    def _hip_optimizer_step(self):
+        from .. import ops as K
+        gs = self.optimizer.param_groups
+        order = self._FLAT_TO_GROUP
+        lr = [gs[j]["lr"] for j in order]
+        mom = [(gs[j]["betas"][0] if self._opt_kind else gs[j]["momentum"]) for j in order]
+        wd = [gs[j]["weight_decay"] for j in order]
+        ema_on = bool(self.ema) and getattr(self.ema, "enabled", True)
+        d = 0.0
+        if ema_on:
+            self.ema.updates += 1
+            d = self.ema.decay(self.ema.updates)
+        amp = self.amp and self.scaler.is_enabled()
+        K.opt_step(self.flat.flat, self.grad_store.flat, self._opt_mom, self._opt_sq,
+                   self.ema.ema_state.flat if ema_on else None, self.flat.flat_buf if ema_on else None,
+                   self.ema.ema_state.flat_buf if ema_on else None, self._opt_ws, [b for _, b in self.flat.group_slices], lr, mom, wd,
+                   self._opt_kind, d, max_norm=10.0,
+                   beta2=gs[0]["betas"][1] if self._opt_kind else 0.999, eps=gs[0].get("eps", 1e-8) if self._opt_kind else 1e-8,
+                   scale=self.scaler._scale if amp else None, growth_tracker=self.scaler._growth_tracker if amp else None,
+                   adam_step=self._adam_step, growth=self.scaler.get_growth_factor() if amp else 2.0,
+                   backoff=self.scaler.get_backoff_factor() if amp else 0.5, interval=self.scaler.get_growth_interval() if amp else 2000)
 
     # ---- the epoch loop (engine/trainer.py:318-474 `_do_train`, without callbacks / plots / logging)
     def fit(self, train_loader, epochs, val_batches=None, save_dir=None, close_mosaic=10, start_epoch=0, lrf=0.01, cos_lr=False,
@@ -223,6 +293,7 @@ class DetectionTrainer:
         flat_layout = all(len(g["params"]) == 1 for g in groups)
         if self.flat is None or flat_layout:
             self.optimizer.load_state_dict(osd)
+            self._adopt_optimizer_state()
             return
         from .flat import _view_like, param_groups
         mine = param_groups(self.model)                                # (decay, norm, bias) lists, reference iteration order
@@ -250,6 +321,7 @@ class DetectionTrainer:
                         _view_like(st[name][off:off + p.numel()], p).copy_(val.to(flat_t.device, torch.float32))
                     elif name == "step":
                         st["step"] = torch.as_tensor(float(val), dtype=torch.float32, device=flat_t.device if self.optimizer.defaults.get("fused") else "cpu")
+        self._adopt_optimizer_state()
 
     # ---- learning-rate schedule and warm-up (engine/trainer.py:209-215, :330, :364-377, :430-433)
     def set_schedule(self, batches_per_epoch, epochs, lrf=0.01, cos_lr=False):
@@ -323,6 +395,9 @@ class DetectionTrainer:
 
     def optimizer_step(self):
         """trainer.py:585-593."""
+        if getattr(self, "_hip_step", False):
+            self._hip_optimizer_step()                   # unscale + norm ; clip + step + EMA + zero_grad + scale update: 2 launches
+            return
         if self.flat is not None:
             for p, g in zip(self.flat_params, self.flat_grads):
                 p.grad = g                               # flat slices of the GradStore buffer

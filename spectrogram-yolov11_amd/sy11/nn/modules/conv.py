@@ -67,16 +67,31 @@ def conv2d_bias_run(ec: Ctx, conv: nn.Conv2d, x: Act, out: Act) -> Act:
             dz = out.grad_read()
             gs = ec.grads
             n = dz.shape[3]
-            if conv.bias is not None and id(conv.bias) in gs.views:
-                one = torch.ones(n, device=ec.device)
-                zero = torch.zeros(n, device=ec.device)
-                scratch = torch.empty(n, device=ec.device)
-                ops.bn_act_bwd_reduce(dz, dz, zero, one, one, zero, False, gs.grad_vec(conv.bias), scratch)
+            has_bias = conv.bias is not None and id(conv.bias) in gs.views
             epc = 16 // torch.empty((), dtype=ec.dtype).element_size()
             npad = -(-n // epc) * epc
             if npad == n and dz.dtype == ec.dtype and (dz.stride(2) * dz.element_size()) % 16 == 0:
-                dy, wk = dz, w
-            else:                                      # pad the channel count to a 16-byte multiple (e.g. nc = 2)
+                dy, wk = dz, w                         # the gradient already is a compute-dtype operand (f32 models)
+                if has_bias:
+                    one = torch.ones(n, device=ec.device)
+                    zero = torch.zeros(n, device=ec.device)
+                    scratch = torch.empty(n, device=ec.device)
+                    ops.bn_act_bwd_reduce(dz, dz, zero, one, one, zero, False, gs.grad_vec(conv.bias), scratch)
+            elif dz.dtype == torch.float32 and npad <= 256:
+                # f32 logit gradient -> 16-bit operand (channel count padded to a 16-byte multiple, e.g. nc = 2 -> 8) and the bias
+                # gradient, in ONE pass (sy11_bias_grad_cast)
+                dy = torch.empty((*dz.shape[:3], npad), dtype=ec.dtype, device=ec.device)
+                ops.bias_grad_cast(dz, dy, gs.grad_vec(conv.bias) if has_bias else None,
+                                   torch.empty((512, n), dtype=torch.float32, device=ec.device) if has_bias else None)
+                wk = w if npad == n else torch.zeros((npad, *w.shape[1:]), dtype=w.dtype, device=w.device)
+                if npad != n:
+                    wk[:n].copy_(w)
+            else:
+                if has_bias:
+                    one = torch.ones(n, device=ec.device)
+                    zero = torch.zeros(n, device=ec.device)
+                    scratch = torch.empty(n, device=ec.device)
+                    ops.bn_act_bwd_reduce(dz, dz, zero, one, one, zero, False, gs.grad_vec(conv.bias), scratch)
                 dy = torch.zeros((*dz.shape[:3], npad), dtype=ec.dtype, device=ec.device)
                 dy[..., :n].copy_(dz)
                 wk = w if npad == n else torch.zeros((npad, *w.shape[1:]), dtype=w.dtype, device=w.device)

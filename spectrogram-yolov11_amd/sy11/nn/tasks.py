@@ -7,7 +7,6 @@ The whole layer graph executes inside ONE engine pass (``EngineFn``): activation
 from __future__ import annotations
 
 import ast
-import contextlib
 import os
 import math
 import re
@@ -248,72 +247,91 @@ def _graph_strides(model, save):
 
 _MODULES = {"Conv": Conv, "DWConv": DWConv, "Bottleneck": Bottleneck, "C2f": C2f, "C3": C3, "C3k": C3k, "C3k2": C3k2,
             "SPPF": SPPF, "C2PSA": C2PSA, "Concat": Concat, "Detect": Detect, "DDWConv": DDWConv, "Fusion": Fusion}
-_BASE = {Conv, DWConv, DDWConv, Bottleneck, C2f, C3, C3k, C3k2, SPPF, C2PSA}
-_REPEAT = {C2f, C3, C3k, C3k2, C2PSA}
+_WIDTH_SCALED = {Conv, DWConv, DDWConv, Bottleneck, C2f, C3, C3k, C3k2, SPPF, C2PSA}       # (c1, c2, ...) constructors: c2 follows the width multiple
+_TAKES_REPEATS = {C2f, C3, C3k, C3k2, C2PSA}                                               # the repeat count is a constructor argument
+
+
+def _model_scale(d):
+    """(depth multiple, width multiple, channel cap, scale letter) of a model dict (tasks.py:968-981)."""
+    scales, letter = d.get("scales"), d.get("scale")
+    if scales:
+        letter = letter or next(iter(scales))
+        depth, width, cap = scales[letter]
+        return depth, width, cap, letter
+    return d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0), float("inf"), letter
+
+
+def _yaml_value(token, names):
+    """A YAML argument: a name the parser knows (`nc`), a Python literal ('None', '[1, 2]'), or the string itself ('nearest')."""
+    if not isinstance(token, str):
+        return token
+    if token in names:
+        return names[token]
+    try:
+        return ast.literal_eval(token)
+    except (ValueError, SyntaxError):
+        return token
+
+
+def _module_class(name):
+    if not isinstance(name, str):
+        return name
+    if name.startswith("nn."):
+        return getattr(torch.nn, name[3:])
+    if name not in _MODULES:
+        raise ops._lib.Sy11Error(f"module '{name}' is outside the MI355X hot path (SURVEY.md §2.1): no HIP kernel")
+    return _MODULES[name]
 
 
 def parse_model(d, ch, verbose=True):
-    """YAML dict -> (nn.Sequential, save list): the channel / depth rules of tasks.py:1085-1101, 1136-1141."""
-    legacy = True
-    max_channels = float("inf")
-    nc, act, scales = (d.get(x) for x in ("nc", "activation", "scales"))
-    depth, width = (d.get(x, 1.0) for x in ("depth_multiple", "width_multiple"))
-    scale = d.get("scale")
-    if scales:
-        if not scale:
-            scale = tuple(scales.keys())[0]
-        depth, width, max_channels = scales[scale]
-    if act:
-        Conv.default_act = eval(act)  # noqa: S307 — same contract as the reference's YAML `activation:` key
-    ch = [ch]
-    layers, save, c2 = [], [], ch[-1]
-    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
-        if isinstance(m, str) and m.startswith("nn."):
-            m = getattr(torch.nn, m[3:])
-        elif isinstance(m, str):
-            if m not in _MODULES:
-                raise ops._lib.Sy11Error(f"module '{m}' is outside the MI355X hot path (SURVEY.md §2.1): no HIP kernel")
-            m = _MODULES[m]
-        args = list(args)
-        for j, a in enumerate(args):
-            if isinstance(a, str):
-                with contextlib.suppress(ValueError):
-                    args[j] = locals()[a] if a in locals() else ast.literal_eval(a)
-        n = n_ = max(round(n * depth), 1) if n > 1 else n
-        if m in _BASE:
-            c1, c2 = ch[f], args[0]
-            if c2 != nc:
-                c2 = make_divisible(min(c2, max_channels) * width, 8)
-            args = [c1, c2, *args[1:]]
-            if m in _REPEAT:
+    """Model dict (YAML) -> (nn.Sequential of layers, sorted list of layer indices whose outputs later layers read).
+    One pass over `backbone + head` rows [from, repeats, module, args]; the channel / depth arithmetic of tasks.py:1085-1141:
+    width-scaled modules get (c_in, round-up-to-8(min(c2, cap) * width), ...), repeat counts scale with depth, Concat sums its
+    inputs, Fusion keeps its first input's width, Detect receives the list of its input widths.  Every layer carries
+    .i / .f / .type / .np (index, sources, class path, parameter count) and .c_out (for the concat planner)."""
+    depth, width, cap, letter = _model_scale(d)
+    nc = d.get("nc")
+    if d.get("activation"):
+        Conv.default_act = eval(d["activation"])  # noqa: S307 — same contract as the reference's YAML `activation:` key
+    known = {"nc": nc}
+    out_ch = []                                    # output width of every layer built so far
+    width_of = lambda j: out_ch[j] if out_ch else ch          # noqa: E731  (layer 0 reads the image)
+    layers, reads, legacy = [], set(), True
+    c_out = ch
+    for i, (src, repeats, name, raw_args) in enumerate(d["backbone"] + d["head"]):
+        cls = _module_class(name)
+        args = [_yaml_value(a, known) for a in raw_args]
+        n = max(round(repeats * depth), 1) if repeats > 1 else repeats
+        if cls in _WIDTH_SCALED:
+            c_out = args[0]
+            if c_out != nc:
+                c_out = make_divisible(min(c_out, cap) * width, 8)
+            args = [width_of(src), c_out, *args[1:]]
+            if cls in _TAKES_REPEATS:
                 args.insert(2, n)
                 n = 1
-            if m is C3k2:
+            if cls is C3k2:                        # the YOLO11 family: non-legacy Detect head; m / l / x always use C3k inside
                 legacy = False
-                if scale in "mlx":
+                if letter in "mlx":
                     args[3] = True
-        elif m is Concat:
-            c2 = sum(ch[x] for x in f)
-        elif m is Fusion:                      # tasks.py:1132-1135: the parser overrides the YAML's fusion type
-            args[0] = "ESChannel"
-            c2 = ch[f[0]]
-            args = [[ch[x] for x in f], args[0]]
-        elif m is Detect:
-            args.append([ch[x] for x in f])
-            m.legacy = legacy
-        else:
-            c2 = ch[f]
-        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
-        t = str(m)[8:-2].replace("__main__.", "")
-        m_.np = sum(x.numel() for x in m_.parameters())
-        m_.i, m_.f, m_.type = i, f, t
-        m_.c_out = c2                                  # output channels (concat planning)
-        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
-        layers.append(m_)
-        if i == 0:
-            ch = []
-        ch.append(c2)
-    return nn.Sequential(*layers), sorted(save)
+        elif cls is Concat:
+            c_out = sum(width_of(j) for j in src)
+        elif cls is Fusion:                        # tasks.py:1132-1135: the parser overrides the YAML's fusion type
+            args = [[width_of(j) for j in src], "ESChannel"]
+            c_out = width_of(src[0])
+        elif cls is Detect:
+            args.append([width_of(j) for j in src])
+            cls.legacy = legacy
+        else:                                      # nn.Upsample & co: width passes through
+            c_out = width_of(src)
+        layer = cls(*args) if n == 1 else nn.Sequential(*[cls(*args) for _ in range(n)])
+        layer.i, layer.f, layer.type = i, src, f"{cls.__module__}.{cls.__qualname__}"
+        layer.np = sum(p.numel() for p in layer.parameters())
+        layer.c_out = c_out
+        reads.update(j % i for j in ([src] if isinstance(src, int) else src) if j != -1)
+        layers.append(layer)
+        out_ch.append(c_out)
+    return nn.Sequential(*layers), sorted(reads)
 
 
 def guess_model_scale(model_path):

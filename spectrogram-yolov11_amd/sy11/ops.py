@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import EPI_ACCUM, EPI_OUT_F32, EPI_SILU, BnTail, ConvDesc, call
+from ._lib import EPI_ACCUM, EPI_OUT_F32, EPI_SILU, BnTail, ConvDesc, OptDesc, call
 
 _DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
 
@@ -220,6 +220,18 @@ def bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx
     call("sy11_bn_act_bwd_apply", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
          _p(scale), _p(shift), _p(gamma), int(silu), _p(sum_g), _p(sum_gx), slots, _p(dy), view_ld(dy), _p(dgamma),
          _p(dbeta), _stream())
+
+
+def bias_grad_cast(dz, dy, dbias=None, partials=None):
+    """dz: f32 NHWC view (B,H,W,N); dy: contiguous (B,H,W,npad) of the compute dtype, npad >= N (pad channels zeroed);
+    dbias: f32 [N] accumulated into.  One launch (two with ``partials``, a [rows][N] scratch selecting the ordered reduction)."""
+    _need_gpu(dz, dy, dbias, partials)
+    M, N = _mc(dz)
+    if dz.dtype != torch.float32 or not dy.is_contiguous() or tuple(dy.shape[:3]) != tuple(dz.shape[:3]) or dy.shape[3] < N:
+        raise _lib.Sy11Error("bias_grad_cast: dz must be f32, dy contiguous with the same pixels and >= N channels")
+    call("sy11_bias_grad_cast", dt_code(dy.dtype), M, N, dy.shape[3], _p(dz), view_ld(dz), _p(dy), _p(dbias), _p(partials),
+         partials.shape[0] if partials is not None else 0, _stream())
+    return dy
 
 
 def copy2d(src, dst, accumulate=False):
@@ -457,9 +469,35 @@ def det_loss_forward(maps, strides, nc, gt):
     return det_loss_terms(det_loss_assign(maps, strides, nc, gt))
 
 
-def det_loss_backward(w: DetLossWorkspace, upstream_over_tss: torch.Tensor, gains, out=None):
-    """d loss / d maps.  ``out``: optional list of NHWC f32 buffers to write into (the captured backward graph's static
-    output-gradient tensors) — used when every shape matches, else fresh tensors are returned."""
+def det_loss_finish(w: DetLossWorkspace, gains):
+    """-> device tensor [loss, box, cls, dfl, 1 / max(tss, 1)] (loss.py:268-275), one launch."""
+    out = torch.empty(5, dtype=torch.float32, device=w.sums.device)
+    call("sy11_det_loss_finish", _p(w.sums), w.B, float(gains[0]), float(gains[1]), float(gains[2]), _p(out), _stream())
+    return out
+
+
+def det_loss_pack_targets(batch_idx, cls, bboxes, B, G, scale_wh):
+    """v8DetectionLoss.preprocess: three (n, ...) f32 device columns -> (B, G, 5) [cls, xyxy pixels]; strided views are fine."""
+    _need_gpu(batch_idx, cls, bboxes)
+    n = batch_idx.shape[0]
+    gt = torch.empty((B, G, 5), dtype=torch.float32, device=batch_idx.device)
+    if n == 0 or G == 0:
+        return gt.zero_() if G else gt
+    for t in (batch_idx, cls, bboxes):
+        if t.dtype != torch.float32:
+            raise _lib.Sy11Error("det_loss_pack_targets: target columns must be f32")
+    bi, cl = batch_idx.reshape(n, -1)[:, 0], cls.reshape(n, -1)[:, 0]
+    if bboxes.dim() != 2 or bboxes.shape[1] != 4 or bboxes.stride(1) != 1:
+        raise _lib.Sy11Error("det_loss_pack_targets: bboxes must be (n, 4) with unit inner stride")
+    call("sy11_det_loss_pack_targets", n, B, G, _p(bi), max(bi.stride(0), 1), _p(cl), max(cl.stride(0), 1), _p(bboxes), max(bboxes.stride(0), 4),
+         float(scale_wh[0]), float(scale_wh[1]), _p(gt), _stream())
+    return gt
+
+
+def det_loss_backward(w: DetLossWorkspace, upstream: torch.Tensor, gains, out=None, inv_tss=None):
+    """d loss / d maps.  ``upstream``: device scalar (upstream gradient; already divided by max(tss, 1) unless ``inv_tss`` — the
+    device scalar 1 / max(tss, 1) of det_loss_finish — is given).  ``out``: optional list of NHWC f32 buffers to write into (the
+    captured backward graph's static output-gradient tensors) — used when every shape matches, else fresh tensors are returned."""
     if out is not None and len(out) == w.nl and all(o.shape == m.shape and o.dtype == m.dtype and o.is_contiguous() for o, m in zip(out, w.maps)):
         dmaps = list(out)
     else:
@@ -467,7 +505,7 @@ def det_loss_backward(w: DetLossWorkspace, upstream_over_tss: torch.Tensor, gain
     dptrs = (C.c_void_p * w.nl)(*[d.data_ptr() for d in dmaps])
     cast = lambda a: C.cast(a, C.c_void_p)
     call("sy11_det_loss_bwd", w.B, w.nc, w.nl, cast(w.ptrs), cast(dptrs), cast(w.hs), cast(w.ws), cast(w.st), w.G, _p(w.gt),
-         _p(w.assign), _p(w.norm), _p(upstream_over_tss), float(gains[0]), float(gains[1]), float(gains[2]), _stream())
+         _p(w.assign), _p(w.norm), _p(upstream), _p(inv_tss), float(gains[0]), float(gains[1]), float(gains[2]), _stream())
     return dmaps
 
 
@@ -520,3 +558,34 @@ def fusion_bwd_apply(dout, x, G_slice, q_slice, S, dmm, amax, dx, accumulate):
     B, H, W, Cn = x.shape
     call("sy11_fusion_bwd_apply", dt_code(x.dtype), B, H * W, Cn, _p(dout), view_ld(dout), _p(x), view_ld(x), _p(G_slice), _p(q_slice),
          G_slice.stride(0), _p(S), _p(dmm), _p(amax), _p(dx), view_ld(dx), int(accumulate), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ trainer step (flat buffers)
+OPT_PARTS = 1024
+
+
+def opt_workspace(device):
+    return torch.zeros(_lib.load().sy11_opt_workspace_floats(OPT_PARTS), dtype=torch.float32, device=device)
+
+
+def opt_step(param, grad, mom, sq, ema, buf, ema_buf, ws, group_end, lr, momentum, weight_decay, kind, ema_decay, max_norm=10.0,
+             beta2=0.999, eps=1e-8, scale=None, growth_tracker=None, adam_step=None, growth=2.0, backoff=0.5, interval=2000,
+             norm_out=None):
+    """engine/trainer.py:585-593 in two launches (csrc/optim.hip): unscale + ||g||, then clip + SGD-nesterov / AdamW + EMA +
+    zero_grad + GradScaler.update.  All tensors are flat f32 device buffers; ``scale`` / ``growth_tracker``: GradScaler's device
+    scalars (None = no AMP); ``ema`` / ``ema_buf`` None = no EMA."""
+    _need_gpu(param, grad, mom, sq, ema, buf, ema_buf, ws)
+    n = param.numel()
+    for t in (grad, mom, sq, ema):
+        if t is not None and (t.numel() != n or t.dtype != torch.float32 or not t.is_contiguous()):
+            raise _lib.Sy11Error("opt_step: grad / mom / sq / ema must be contiguous f32 buffers of the parameter buffer's length")
+    d = OptDesc()
+    d.n, d.n_buf = n, (buf.numel() if (buf is not None and ema_buf is not None) else 0)
+    for k in range(3):
+        d.group_end[k], d.lr[k], d.momentum[k], d.weight_decay[k] = int(group_end[k]), float(lr[k]), float(momentum[k]), float(weight_decay[k])
+    d.kind, d.beta2, d.eps, d.max_norm, d.ema_decay = int(kind), float(beta2), float(eps), float(max_norm), float(ema_decay)
+    d.amp = int(scale is not None)
+    d.growth_factor, d.backoff_factor, d.growth_interval, d.nparts = float(growth), float(backoff), int(interval), OPT_PARTS
+    call("sy11_opt_grad_norm", n, _p(grad), _p(scale), _p(adam_step), _p(ws), OPT_PARTS, _stream())
+    call("sy11_opt_step", C.byref(d), _p(param), _p(grad), _p(mom), _p(sq), _p(ema), _p(buf) if d.n_buf else None,
+         _p(ema_buf) if d.n_buf else None, _p(ws), _p(scale), _p(growth_tracker), _p(adam_step), _p(norm_out), _stream())

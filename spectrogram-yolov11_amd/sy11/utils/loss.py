@@ -7,11 +7,11 @@ from __future__ import annotations
 
 import torch
 
-from .ops import xywh2xyxy
 
 
 class _FusedLossFn(torch.autograd.Function):
-    """Whole criterion as 5 HIP launches forward + 1 backward (csrc/loss.hip); no host synchronisation."""
+    """Whole criterion as 6 HIP launches forward (decode, metrics, resolve, norm, terms, finish) + 1 backward (csrc/loss.hip);
+    no host synchronisation, no tensor-op glue."""
 
     @staticmethod
     def forward(ctx, crit, gt, *feats):
@@ -19,15 +19,9 @@ class _FusedLossFn(torch.autograd.Function):
         maps = [f.permute(0, 2, 3, 1) for f in feats]
         maps = [m if m.is_contiguous() else m.contiguous() for m in maps]
         w = K.det_loss_forward(maps, crit.stride_f, crit.nc, gt)
-        tot = w.sums.sum(0)                                     # [tss, box, cls, dfl]
-        tss = tot[0].clamp(min=1.0)
-        items = tot[1:4] / tss
-        gains = torch.tensor([crit.hyp.box, crit.hyp.cls, crit.hyp.dfl], dtype=torch.float32).to(items.device, non_blocking=True) \
-            if crit._gains is None else crit._gains
-        crit._gains = gains
-        items = items * gains
-        ctx.w, ctx.tss, ctx.crit = w, tss, crit
-        loss = items.sum() * feats[0].shape[0]
+        out = K.det_loss_finish(w, (crit.hyp.box, crit.hyp.cls, crit.hyp.dfl))       # [loss, box, cls, dfl, 1 / max(tss, 1)]
+        ctx.w, ctx.inv_tss, ctx.crit = w, out[4:5], crit
+        loss, items = out[0], out[1:4]
         ctx.mark_non_differentiable(items)
         return loss, items
 
@@ -35,8 +29,9 @@ class _FusedLossFn(torch.autograd.Function):
     def backward(ctx, gloss, gitems):
         from .. import ops as K
         crit = ctx.crit
-        up = (gloss.float() / ctx.tss).reshape(1).contiguous()
-        dmaps = K.det_loss_backward(ctx.w, up, (crit.hyp.box, crit.hyp.cls, crit.hyp.dfl), out=crit.__dict__.get("grad_out"))
+        up = gloss if gloss.dtype == torch.float32 else gloss.float()
+        dmaps = K.det_loss_backward(ctx.w, up.reshape(1), (crit.hyp.box, crit.hyp.cls, crit.hyp.dfl), out=crit.__dict__.get("grad_out"),
+                                    inv_tss=ctx.inv_tss)
         return (None, None, *[d.permute(0, 3, 1, 2) for d in dmaps])
 
 
@@ -81,28 +76,35 @@ class v8DetectionLoss:
 
     def preprocess(self, targets, batch_size, scale_tensor, batch_idx=None):
         """(n, 6) [image, cls, xywh normalised] -> (B, max targets per image, 5) [cls, xyxy pixels], zero padded
-        (utils/loss.py:194-207) without the per-image host loop."""
+        (utils/loss.py:194-207): one HIP launch (sy11_det_loss_pack_targets) instead of the per-image host loop."""
+        from .. import ops as K
         nl, ne = targets.shape
         if nl == 0:
             return torch.zeros(batch_size, 0, ne - 1, device=self.device)
-        i = targets[:, 0].long()
         src = batch_idx if batch_idx is not None else targets[:, 0]
         if not src.is_cuda:                                  # labels still on the host: count there, nothing to wait for
-            counts_h = torch.bincount(src.long().view(-1), minlength=batch_size)
-            n_max = self._max_targets(src, counts_h)
-            counts = counts_h.to(i.device)
+            n_max = self._max_targets(src, torch.bincount(src.long().view(-1), minlength=batch_size))
         else:
-            # scatter-add, not torch.bincount: bincount on a device tensor reads max(i) back to size its output
-            counts = torch.zeros(batch_size, dtype=torch.long, device=i.device).scatter_add_(0, i, torch.ones_like(i))
-            n_max = self._max_targets(src, counts)
-        out = torch.zeros(batch_size, n_max, ne - 1, device=self.device)
-        order = torch.argsort(i, stable=True)                # rank of each target inside its image, original order kept
-        starts = torch.cumsum(counts, 0) - counts
-        rank = torch.empty_like(i)
-        rank[order] = torch.arange(nl, device=i.device) - starts[i[order]]
-        out[i, rank.clamp_(max=n_max - 1)] = targets[:, 1:]  # the clamp makes an out-of-bounds write impossible by construction
-        out[..., 1:5] = xywh2xyxy(out[..., 1:5].mul_(scale_tensor))
-        return out
+            # scatter-add, not torch.bincount: bincount on a device tensor reads max(i) back to size its output; the count is
+            # taken ONCE per label tensor object (_max_targets)
+            hit = self.__dict__.setdefault("_max_gt_cache", {}).get(id(src))
+            if hit is not None and hit[0]() is src and hit[1] == src._version:
+                n_max = hit[2]
+            else:
+                i = targets[:, 0].long()
+                counts = torch.zeros(batch_size, dtype=torch.long, device=i.device).scatter_add_(0, i, torch.ones_like(i))
+                n_max = self._max_targets(src, counts)
+        t = targets.to(self.device, non_blocking=True)
+        sw, sh = (float(v) for v in scale_tensor[:2]) if not torch.is_tensor(scale_tensor) else self._scale_wh(scale_tensor)
+        return K.det_loss_pack_targets(t[:, 0], t[:, 1], t[:, 2:6], batch_size, n_max, (sw, sh))
+
+    def _scale_wh(self, scale_tensor):
+        key = (scale_tensor.data_ptr(), scale_tensor._version)
+        c = self.__dict__.setdefault("_scale_wh_cache", {})
+        if key not in c:
+            v = scale_tensor.detach().cpu()
+            c[key] = (float(v[0]), float(v[1]))
+        return c[key]
 
     def __call__(self, preds, batch):
         feats = preds[1] if isinstance(preds, tuple) else preds
@@ -112,11 +114,10 @@ class v8DetectionLoss:
             raise _lib.Sy11Error("v8DetectionLoss: the HIP criterion needs CUDA f32 head maps (got "
                                  f"{[(str(f.device), str(f.dtype)) for f in feats]})")
         hw = tuple(feats[0].shape[2:])
-        scales = self.__dict__.setdefault("_scale_cache", {})
-        if hw not in scales:                                 # (w, h, w, h) in pixels, uploaded once per input size
-            imgsz = torch.tensor(hw, dtype=torch.float32) * self.stride_f[0]
-            scales[hw] = imgsz[[1, 0, 1, 0]].to(self.device)
-        targets = torch.cat((batch["batch_idx"].view(-1, 1), batch["cls"].view(-1, 1), batch["bboxes"]), 1)
-        gt = self.preprocess(targets.to(self.device).float(), B, scale_tensor=scales[hw], batch_idx=batch["batch_idx"])
+        scale_wh = (hw[1] * self.stride_f[0], hw[0] * self.stride_f[0])         # image (w, h) in pixels: loss.py:233
+        parts = (batch["batch_idx"].view(-1, 1), batch["cls"].view(-1, 1), batch["bboxes"])
+        # host labels (the dataloader case): one host-side cat + ONE upload; device labels: one cat launch
+        targets = torch.cat([p.float() for p in parts], 1)
+        gt = self.preprocess(targets, B, scale_tensor=scale_wh, batch_idx=batch["batch_idx"])
         loss, items = _FusedLossFn.apply(self, gt, *feats)
         return loss, items.detach()

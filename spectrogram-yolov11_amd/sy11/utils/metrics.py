@@ -1,154 +1,127 @@
-"""bbox_iou with the reference's signature (ultralytics/utils/metrics.py:171-234): IoU / GIoU / DIoU / CIoU.
-Gotcha kept: in xyxy mode h gets +eps, w does not; union += eps; CIoU alpha under no_grad."""
+"""Validation metrics under the reference's names (ultralytics/utils/metrics.py: box_iou :52-72, smooth :547-552, compute_ap :605-634,
+ap_per_class :637-725, Metric :728-851, DetMetrics :898-1000).
+
+The IoU matrix of a validation image runs on the device (``box_iou_device`` -> sy11_box_iou, bit-identical to the reference's
+evaluation order); the precision / recall bookkeeping runs once per validation pass over a few thousand rows and stays in numpy.
+(The training criterion's CIoU lives inside csrc/loss.hip; there is no tensor-op ``bbox_iou`` in this package.)
+"""
 from __future__ import annotations
 
-import math
-
+import numpy as np
 import torch
 
-
-def bbox_iou(box1, box2, xywh=True, GIoU=False, DIoU=False, CIoU=False, eps=1e-7):
-    if xywh:
-        (x1, y1, w1, h1), (x2, y2, w2, h2) = box1.chunk(4, -1), box2.chunk(4, -1)
-        b1_x1, b1_x2, b1_y1, b1_y2 = x1 - w1 / 2, x1 + w1 / 2, y1 - h1 / 2, y1 + h1 / 2
-        b2_x1, b2_x2, b2_y1, b2_y2 = x2 - w2 / 2, x2 + w2 / 2, y2 - h2 / 2, y2 + h2 / 2
-    else:
-        b1_x1, b1_y1, b1_x2, b1_y2 = box1.chunk(4, -1)
-        b2_x1, b2_y1, b2_x2, b2_y2 = box2.chunk(4, -1)
-        w1, h1 = b1_x2 - b1_x1, b1_y2 - b1_y1 + eps
-        w2, h2 = b2_x2 - b2_x1, b2_y2 - b2_y1 + eps
-    inter = (b1_x2.minimum(b2_x2) - b1_x1.maximum(b2_x1)).clamp_(0) * (b1_y2.minimum(b2_y2) - b1_y1.maximum(b2_y1)).clamp_(0)
-    union = w1 * h1 + w2 * h2 - inter + eps
-    iou = inter / union
-    if CIoU or DIoU or GIoU:
-        cw = b1_x2.maximum(b2_x2) - b1_x1.minimum(b2_x1)
-        ch = b1_y2.maximum(b2_y2) - b1_y1.minimum(b2_y1)
-        if CIoU or DIoU:
-            c2 = cw.pow(2) + ch.pow(2) + eps
-            rho2 = ((b2_x1 + b2_x2 - b1_x1 - b1_x2).pow(2) + (b2_y1 + b2_y2 - b1_y1 - b1_y2).pow(2)) / 4
-            if CIoU:
-                v = (4 / math.pi**2) * ((w2 / h2).atan() - (w1 / h1).atan()).pow(2)
-                with torch.no_grad():
-                    alpha = v / (v - iou + (1 + eps))
-                return iou - (rho2 / c2 + v * alpha)
-            return iou - rho2 / c2
-        c_area = cw * ch + eps
-        return iou - (c_area - union) / c_area
-    return iou
+_trapezoid = getattr(np, "trapezoid", None) or np.trapz
+_RECALL_GRID = np.linspace(0.0, 1.0, 101)          # COCO's 101 recall points
+_CONF_GRID = np.linspace(0.0, 1.0, 1000)           # confidence axis of the P / R / F1 curves
 
 
 def box_iou(box1, box2, eps=1e-7):
-    """(N,4) x (M,4) xyxy -> (N,M) IoU (metrics.py:52-72)."""
-    (a1, a2), (b1, b2) = box1.float().unsqueeze(1).chunk(2, 2), box2.float().unsqueeze(0).chunk(2, 2)
-    inter = (torch.min(a2, b2) - torch.max(a1, b1)).clamp_(0).prod(2)
-    return inter / ((a2 - a1).prod(2) + (b2 - b1).prod(2) - inter + eps)
-
-
-# ------------------------------------------------------------------------------------------------ validation metrics
-# The reference's mAP machinery (utils/metrics.py:547-552 smooth, :605-634 compute_ap, :637-725 ap_per_class, :728-851
-# Metric, :898-1000 DetMetrics).  box_iou runs on the device through the C-ABI; the PR-curve arithmetic is host-side
-# numpy exactly as in the reference (it runs once per validation pass over a few thousand rows).
-import numpy as np  # noqa: E402
+    """(N, 4) x (M, 4) xyxy -> (N, M) IoU, tensor formulation (host-side stand-in of ``box_iou_device``; same rounding steps:
+    width * height, area sum minus intersection, plus eps)."""
+    a, b = box1.float(), box2.float()
+    span = (torch.minimum(a[:, None, 2:], b[None, :, 2:]) - torch.maximum(a[:, None, :2], b[None, :, :2])).clamp_(min=0)
+    inter = span[..., 0] * span[..., 1]
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (area_a[:, None] + area_b[None, :] - inter + eps)
 
 
 def box_iou_device(box1: torch.Tensor, box2: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
-    """box_iou (metrics.py:52-72) through sy11_box_iou: (N,4) x (M,4) xyxy on the GPU -> (N,M) f32, bit-identical to the
-    reference's evaluation order."""
+    """box_iou through sy11_box_iou: (N, 4) x (M, 4) xyxy on the GPU -> (N, M) f32."""
     from .. import ops
     a, b = box1.float().contiguous(), box2.float().contiguous()
-    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
     ops._need_gpu(a, b)
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
     ops.call("sy11_box_iou", a.shape[0], b.shape[0], ops._p(a), ops._p(b), float(eps), ops._p(out), ops._stream())
     return out
 
 
 def smooth(y, f=0.05):
-    """Box filter of fraction f with edge replication (metrics.py:547-552)."""
-    nf = round(len(y) * f * 2) // 2 + 1
-    pad = np.ones(nf // 2)
-    return np.convolve(np.concatenate((pad * y[0], y, pad * y[-1])), np.ones(nf) / nf, mode="valid")
-
-
-_trapz = getattr(np, "trapezoid", None) or np.trapz
+    """Moving average over a window of about ``f`` of the curve (odd length), the ends extended by their edge values."""
+    width = round(len(y) * f * 2) // 2 + 1
+    edge = width // 2
+    padded = np.concatenate((np.full(edge, y[0], dtype=float), y, np.full(edge, y[-1], dtype=float)))
+    return np.convolve(padded, np.full(width, 1.0 / width), mode="valid")
 
 
 def compute_ap(recall, precision):
-    """101-point interpolated area under the monotone precision envelope, sentinels (0,1) and (1,0) (metrics.py:605-634)."""
-    mrec = np.concatenate(([0.0], recall, [1.0]))
-    mpre = np.concatenate(([1.0], precision, [0.0]))
-    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
-    x = np.linspace(0, 1, 101)
-    return _trapz(np.interp(x, mrec, mpre), x), mpre, mrec
+    """Average precision of one PR curve: sentinels (0, 1) / (1, 0), the monotone (right-to-left running maximum) precision
+    envelope, area under its 101-point interpolation.  -> (ap, envelope, recall with sentinels)."""
+    rec = np.concatenate(([0.0], recall, [1.0]))
+    env = np.maximum.accumulate(np.concatenate(([1.0], precision, [0.0]))[::-1])[::-1]
+    return _trapezoid(np.interp(_RECALL_GRID, rec, env), _RECALL_GRID), env, rec
+
+
+def _class_curves(tp_c, conf_c, n_labels, eps):
+    """One class: cumulative TP / FP over its detections (already in descending confidence) -> recall (n, T), precision (n, T)
+    and both sampled on the confidence grid at the first IoU threshold."""
+    hits = tp_c.cumsum(0)
+    misses = (1 - tp_c).cumsum(0)
+    recall = hits / (n_labels + eps)
+    precision = hits / (hits + misses)
+    # np.interp wants increasing abscissae: walk the confidences negated
+    r_grid = np.interp(-_CONF_GRID, -conf_c, recall[:, 0], left=0)
+    p_grid = np.interp(-_CONF_GRID, -conf_c, precision[:, 0], left=1)
+    return recall, precision, r_grid, p_grid
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
-    """Per-class AP at every IoU threshold plus the P / R / F1 curves (metrics.py:637-725, plotting dropped).
-    Returns (tp, fp, p, r, f1, ap, unique_classes, p_curve, r_curve, f1_curve, x, prec_values)."""
-    order = np.argsort(-conf)
-    tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
-    classes, n_targets = np.unique(target_cls, return_counts=True)
-    nc = classes.shape[0]
-    x, prec_values = np.linspace(0, 1, 1000), []
-    ap = np.zeros((nc, tp.shape[1]))
-    p_curve, r_curve = np.zeros((nc, 1000)), np.zeros((nc, 1000))
-    for ci, c in enumerate(classes):
-        sel = pred_cls == c
-        n_l, n_p = n_targets[ci], sel.sum()
-        if n_p == 0 or n_l == 0:
+    """AP per class and IoU threshold plus the P / R / F1 operating point at the F1-optimal confidence (plotting dropped).
+    tp (n, T) bool, conf (n,), pred_cls (n,), target_cls (m,).
+    -> (tp count, fp count, p, r, f1, ap (classes, T), classes, p_curve, r_curve, f1_curve, confidence grid, PR curves at T0)."""
+    rank = np.argsort(-conf)
+    tp, conf, pred_cls = tp[rank], conf[rank], pred_cls[rank]
+    classes, n_labels = np.unique(target_cls, return_counts=True)
+    n_cls, n_thr = classes.shape[0], tp.shape[1]
+    ap = np.zeros((n_cls, n_thr))
+    p_curve = np.zeros((n_cls, _CONF_GRID.size))
+    r_curve = np.zeros_like(p_curve)
+    pr_at_t0 = []
+    for k in range(n_cls):
+        mine = pred_cls == classes[k]
+        if not mine.any() or n_labels[k] == 0:
             continue
-        fpc = (1 - tp[sel]).cumsum(0)
-        tpc = tp[sel].cumsum(0)
-        recall = tpc / (n_l + eps)
-        r_curve[ci] = np.interp(-x, -conf[sel], recall[:, 0], left=0)      # xp must increase: negate the confidences
-        precision = tpc / (tpc + fpc)
-        p_curve[ci] = np.interp(-x, -conf[sel], precision[:, 0], left=1)
-        for j in range(tp.shape[1]):
-            ap[ci, j], mpre, mrec = compute_ap(recall[:, j], precision[:, j])
-            if j == 0:
-                prec_values.append(np.interp(x, mrec, mpre))
-    prec_values = np.array(prec_values)
+        recall, precision, r_curve[k], p_curve[k] = _class_curves(tp[mine], conf[mine], n_labels[k], eps)
+        for t in range(n_thr):
+            ap[k, t], env, rec = compute_ap(recall[:, t], precision[:, t])
+            if t == 0:
+                pr_at_t0.append(np.interp(_CONF_GRID, rec, env))
     f1_curve = 2 * p_curve * r_curve / (p_curve + r_curve + eps)
-    i = smooth(f1_curve.mean(0), 0.1).argmax()
-    p, r, f1 = p_curve[:, i], r_curve[:, i], f1_curve[:, i]
-    tpn = (r * n_targets).round()
-    fpn = (tpn / (p + eps) - tpn).round()
-    return tpn, fpn, p, r, f1, ap, classes.astype(int), p_curve, r_curve, f1_curve, x, prec_values
+    best = smooth(f1_curve.mean(0), 0.1).argmax()                 # one confidence for all classes: the smoothed mean-F1 peak
+    p, r, f1 = p_curve[:, best], r_curve[:, best], f1_curve[:, best]
+    n_tp = (r * n_labels).round()
+    n_fp = (n_tp / (p + eps) - n_tp).round()
+    return n_tp, n_fp, p, r, f1, ap, classes.astype(int), p_curve, r_curve, f1_curve, _CONF_GRID, np.array(pr_at_t0)
 
 
 class Metric:
-    """Per-class P / R / F1 / AP container with the reference's accessors (metrics.py:728-896)."""
+    """Per-class precision / recall / F1 / AP of one task with the reference's accessor names."""
+
+    _FITNESS_WEIGHTS = np.array([0.0, 0.0, 0.1, 0.9])     # (P, R, mAP@0.5, mAP@0.5:0.95)
 
     def __init__(self):
-        self.p, self.r, self.f1, self.all_ap, self.ap_class_index = [], [], [], [], []
+        self.p = self.r = self.f1 = self.all_ap = self.ap_class_index = ()
         self.nc = 0
 
-    @property
-    def ap50(self):
-        return self.all_ap[:, 0] if len(self.all_ap) else []
+    def update(self, results):
+        """results = (p, r, f1, all_ap, ap_class_index, ...) as ap_per_class()[2:] delivers them."""
+        self.p, self.r, self.f1, self.all_ap, self.ap_class_index = results[:5]
 
-    @property
-    def ap(self):
-        return self.all_ap.mean(1) if len(self.all_ap) else []
+    def _ap_columns(self, cols=None):
+        """Mean over classes of the AP columns ``cols`` (None: all thresholds); 0.0 before the first update."""
+        if not len(self.all_ap):
+            return 0.0
+        return float(np.mean(self.all_ap if cols is None else self.all_ap[:, cols]))
 
-    @property
-    def mp(self):
-        return self.p.mean() if len(self.p) else 0.0
-
-    @property
-    def mr(self):
-        return self.r.mean() if len(self.r) else 0.0
-
-    @property
-    def map50(self):
-        return self.all_ap[:, 0].mean() if len(self.all_ap) else 0.0
-
-    @property
-    def map75(self):
-        return self.all_ap[:, 5].mean() if len(self.all_ap) else 0.0
-
-    @property
-    def map(self):
-        return self.all_ap.mean() if len(self.all_ap) else 0.0
+    # per class
+    ap50 = property(lambda self: self.all_ap[:, 0] if len(self.all_ap) else [])
+    ap = property(lambda self: self.all_ap.mean(1) if len(self.all_ap) else [])
+    # means over classes
+    mp = property(lambda self: float(np.mean(self.p)) if len(self.p) else 0.0)
+    mr = property(lambda self: float(np.mean(self.r)) if len(self.r) else 0.0)
+    map50 = property(lambda self: self._ap_columns(0))
+    map75 = property(lambda self: self._ap_columns(5))
+    map = property(lambda self: self._ap_columns())
 
     def mean_results(self):
         return [self.mp, self.mr, self.map50, self.map]
@@ -158,35 +131,30 @@ class Metric:
 
     @property
     def maps(self):
-        maps = np.zeros(self.nc) + self.map
-        for i, c in enumerate(self.ap_class_index):
-            maps[c] = self.ap[i]
-        return maps
+        """mAP@0.5:0.95 per class id: the overall value where a class had no labels."""
+        out = np.full(self.nc, self.map, dtype=float)
+        if len(self.ap_class_index):
+            out[np.asarray(self.ap_class_index, int)] = self.ap
+        return out
 
     def fitness(self):
-        return (np.array(self.mean_results()) * [0.0, 0.0, 0.1, 0.9]).sum()
-
-    def update(self, results):
-        self.p, self.r, self.f1, self.all_ap, self.ap_class_index = results[:5]
+        return float((np.asarray(self.mean_results()) * self._FITNESS_WEIGHTS).sum())
 
 
 class DetMetrics:
-    """Detection metrics with the reference's public surface (metrics.py:898-1000): process(), keys, results_dict, fitness."""
+    """Detection metrics facade: ``process`` the accumulated statistics, then read ``results_dict`` / ``fitness`` / ``maps``."""
+
+    keys = ["metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)"]
+    task = "detect"
 
     def __init__(self, names=()):
         self.names = names
         self.box = Metric()
-        self.speed = {"preprocess": 0.0, "inference": 0.0, "loss": 0.0, "postprocess": 0.0}
-        self.task = "detect"
+        self.speed = dict.fromkeys(("preprocess", "inference", "loss", "postprocess"), 0.0)
 
     def process(self, tp, conf, pred_cls, target_cls):
-        res = ap_per_class(tp, conf, pred_cls, target_cls)[2:]
         self.box.nc = len(self.names)
-        self.box.update(res)
-
-    @property
-    def keys(self):
-        return ["metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)"]
+        self.box.update(ap_per_class(tp, conf, pred_cls, target_cls)[2:])
 
     def mean_results(self):
         return self.box.mean_results()
@@ -194,18 +162,11 @@ class DetMetrics:
     def class_result(self, i):
         return self.box.class_result(i)
 
-    @property
-    def maps(self):
-        return self.box.maps
-
-    @property
-    def fitness(self):
-        return self.box.fitness()
-
-    @property
-    def ap_class_index(self):
-        return self.box.ap_class_index
+    maps = property(lambda self: self.box.maps)
+    fitness = property(lambda self: self.box.fitness())
+    ap_class_index = property(lambda self: self.box.ap_class_index)
 
     @property
     def results_dict(self):
-        return dict(zip(self.keys + ["fitness"], self.mean_results() + [self.fitness]))
+        values = self.mean_results() + [self.fitness]
+        return dict(zip(self.keys + ["fitness"], values))

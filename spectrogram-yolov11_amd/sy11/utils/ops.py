@@ -1,9 +1,12 @@
-"""Box utilities and NMS with the reference's names (ultralytics/utils/ops.py: scale_boxes :92-127,
-make_divisible :130-143, non_max_suppression :181-332, clip_boxes :335-354, xyxy2xywh :412-429, xywh2xyxy :432-449).
+"""Box utilities and NMS under the reference's names (ultralytics/utils/ops.py: scale_boxes :92-127, make_divisible :130-143,
+non_max_suppression :181-332, clip_boxes :335-354, xyxy2xywh :412-429, xywh2xyxy :432-449).
 
-``non_max_suppression`` keeps the reference's candidate selection / class offset / truncation, and replaces
-``torchvision.ops.nms`` (ops.py:312) by the HIP bit-matrix kernel (sy11_nms_sorted) fed in (score desc, index asc)
-order.  The wall-clock break of the reference (ops.py:328-330) is intentionally absent: results never depend on time.
+``non_max_suppression`` is re-cut for the device: candidate selection, class offsets, the per-image score ordering and the
+`max_nms` / `max_det` truncations are done ONCE for the whole batch with tensor ops (one host read of the per-image candidate
+counts instead of a Python loop with several reads per image); only the greedy suppression itself runs per image, on the HIP
+bit-matrix kernel (``sy11_nms_sorted``) that stands where the reference calls ``torchvision.ops.nms`` (ops.py:312), fed in
+(score descending, index ascending) order so the kept set is bit-exact.  The reference's wall-clock break (ops.py:328-330) is
+intentionally absent: results never depend on time.
 """
 from __future__ import annotations
 
@@ -15,51 +18,50 @@ from .. import ops as _k
 
 
 def make_divisible(x, divisor):
-    if isinstance(divisor, torch.Tensor):
-        divisor = int(divisor.max())
-    return math.ceil(x / divisor) * divisor
+    """Smallest multiple of ``divisor`` (an int or a stride tensor: its maximum) that is >= x."""
+    d = int(divisor.max()) if isinstance(divisor, torch.Tensor) else divisor
+    return d * math.ceil(x / d)
+
+
+def _need_boxes(x):
+    if x.shape[-1] != 4:
+        raise AssertionError(f"input shape last dimension expected 4 but input shape is {x.shape}")
 
 
 def xywh2xyxy(x):
-    assert x.shape[-1] == 4, f"input shape last dimension expected 4 but input shape is {x.shape}"
-    y = torch.empty_like(x)
-    xy, wh = x[..., :2], x[..., 2:] / 2
-    y[..., :2] = xy - wh
-    y[..., 2:] = xy + wh
-    return y
+    """(cx, cy, w, h) -> (x1, y1, x2, y2), last dimension 4; a new tensor."""
+    _need_boxes(x)
+    centre, half = x[..., :2], x[..., 2:] / 2
+    return torch.cat((centre - half, centre + half), -1)
 
 
 def xyxy2xywh(x):
-    assert x.shape[-1] == 4, f"input shape last dimension expected 4 but input shape is {x.shape}"
-    y = torch.empty_like(x)
-    y[..., 0] = (x[..., 0] + x[..., 2]) / 2
-    y[..., 1] = (x[..., 1] + x[..., 3]) / 2
-    y[..., 2] = x[..., 2] - x[..., 0]
-    y[..., 3] = x[..., 3] - x[..., 1]
-    return y
+    """(x1, y1, x2, y2) -> (cx, cy, w, h), last dimension 4; a new tensor."""
+    _need_boxes(x)
+    lo, hi = x[..., :2], x[..., 2:]
+    return torch.cat(((lo + hi) / 2, hi - lo), -1)
 
 
 def clip_boxes(boxes, shape):
-    boxes[..., 0] = boxes[..., 0].clamp(0, shape[1])
-    boxes[..., 1] = boxes[..., 1].clamp(0, shape[0])
-    boxes[..., 2] = boxes[..., 2].clamp(0, shape[1])
-    boxes[..., 3] = boxes[..., 3].clamp(0, shape[0])
+    """Clamp xyxy boxes into an image of ``shape`` = (h, w), in place: x columns to [0, w], y columns to [0, h]."""
+    h, w = shape[0], shape[1]
+    boxes[..., 0:4:2].clamp_(0, w)          # strided views of columns (0, 2) and (1, 3): in place, no gather
+    boxes[..., 1:4:2].clamp_(0, h)
     return boxes
 
 
 def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None, padding=True, xywh=False):
-    if ratio_pad is None:
-        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
-        pad = (round((img1_shape[1] - img0_shape[1] * gain) / 2 - 0.1), round((img1_shape[0] - img0_shape[0] * gain) / 2 - 0.1))
+    """Boxes of the letterboxed ``img1_shape`` back to the original ``img0_shape``, in place: remove the border, undo the gain, clip."""
+    if ratio_pad is not None:
+        gain, (pad_x, pad_y) = ratio_pad[0][0], ratio_pad[1]
     else:
-        gain = ratio_pad[0][0]
-        pad = ratio_pad[1]
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad_x = round((img1_shape[1] - img0_shape[1] * gain) / 2 - 0.1)
+        pad_y = round((img1_shape[0] - img0_shape[0] * gain) / 2 - 0.1)
     if padding:
-        boxes[..., 0] -= pad[0]
-        boxes[..., 1] -= pad[1]
-        if not xywh:
-            boxes[..., 2] -= pad[0]
-            boxes[..., 3] -= pad[1]
+        last = 2 if xywh else 4             # xywh: only the centre moves
+        boxes[..., 0:last:2] -= pad_x
+        boxes[..., 1:last:2] -= pad_y
     boxes[..., :4] /= gain
     return clip_boxes(boxes, img0_shape)
 
@@ -73,53 +75,111 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
     return order[keep]
 
 
+def _suppress(boxes_sorted, scores_sorted, iou_threshold):
+    """Greedy suppression of ONE image's candidates, already in (score descending, candidate order) order -> bool keep mask.
+    (``scores_sorted`` is not needed by the kernel: the order carries it.  Kept in the signature for the parity tests, which
+    intercept this call to compare the rows with what the reference hands to torchvision.ops.nms.)"""
+    return _k.nms_sorted(boxes_sorted, float(iou_threshold))
+
+
+def _prior_rows(labels, nc, nm, dtype, device):
+    """The reference's apriori-label rows (ops.py:272-278): one (4 + nc + nm) row per given label — its box in xyxy, a one-hot
+    class vector — appended after an image's predictions.  -> (image index, rows) or None."""
+    img, rows = [], []
+    for xi, lb in enumerate(labels or ()):
+        if lb is None or len(lb) == 0:
+            continue
+        lb = torch.as_tensor(lb, dtype=dtype, device=device)
+        v = torch.zeros((lb.shape[0], 4 + nc + nm), dtype=dtype, device=device)
+        v[:, :4] = xywh2xyxy(lb[:, 1:5])
+        v[torch.arange(lb.shape[0], device=device), lb[:, 0].long() + 4] = 1.0
+        img.append(torch.full((lb.shape[0],), xi, dtype=torch.long, device=device))
+        rows.append(v)
+    return (torch.cat(img), torch.cat(rows)) if rows else None
+
+
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
                         labels=(), max_det=300, nc=0, max_time_img=0.05, max_nms=30000, max_wh=7680, in_place=True,
                         rotated=False, end2end=False):
-    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
-    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
-    if rotated or labels:
-        raise NotImplementedError("rotated boxes / apriori labels are outside the hot path")
-    if isinstance(prediction, (list, tuple)):
+    """(B, 4 + nc + nm, A) predictions -> list of B tensors (n_i, 6 + nm) [x1, y1, x2, y2, score, class, mask coefficients],
+    rows in descending-score order, at most ``max_det`` per image.  Same arguments and results as the reference's."""
+    for name, v in (("Confidence threshold", conf_thres), ("IoU", iou_thres)):
+        if not 0 <= v <= 1:
+            raise AssertionError(f"Invalid {name} {v}, valid values are between 0.0 and 1.0")
+    if rotated:
+        raise NotImplementedError("rotated boxes are outside the hot path")
+    if isinstance(prediction, (list, tuple)):                 # (inference output, raw maps)
         prediction = prediction[0]
-    if classes is not None:
-        classes = torch.tensor(classes, device=prediction.device)
-    if prediction.shape[-1] == 6 or end2end:
-        output = [pred[pred[:, 4] > conf_thres][:max_det] for pred in prediction]
-        if classes is not None:
-            output = [pred[(pred[:, 5:6] == classes).any(1)] for pred in output]
-        return output
-    bs = prediction.shape[0]
-    nc = nc or (prediction.shape[1] - 4)
-    nm = prediction.shape[1] - nc - 4
-    mi = 4 + nc
-    xc = prediction[:, 4:mi].amax(1) > conf_thres
-    multi_label &= nc > 1
-    prediction = prediction.transpose(-1, -2)
+    dev = prediction.device
+    wanted = None if classes is None else torch.as_tensor(classes, device=dev)
+    if prediction.shape[-1] == 6 or end2end:                  # already one row per detection: threshold only
+        out = []
+        for rows in prediction:
+            rows = rows[rows[:, 4] > conf_thres][:max_det]
+            out.append(rows if wanted is None else rows[(rows[:, 5:6] == wanted).any(1)])
+        return out
+
+    B, D, A = prediction.shape
+    nc = nc or D - 4
+    nm = D - 4 - nc
+    multi_label = bool(multi_label) and nc > 1
+    rows = prediction.transpose(1, 2)                         # (B, A, D) view
+    xyxy = xywh2xyxy(rows[..., :4])
     if in_place:
-        prediction[..., :4] = xywh2xyxy(prediction[..., :4])
+        rows[..., :4] = xyxy                                  # the caller's tensor holds corner boxes afterwards, as in the reference
+    rows = torch.cat((xyxy, rows[..., 4:]), -1).reshape(B * A, D)
+    img_of = torch.arange(B, device=dev).repeat_interleave(A)
+    prior = _prior_rows(labels, nc, nm, rows.dtype, dev)
+    if prior is not None:                                     # an image's apriori rows follow its predictions (stable sort below)
+        img_of = torch.cat((img_of, prior[0]))
+        rows = torch.cat((rows, prior[1]))
+        order = torch.sort(img_of, stable=True).indices
+        img_of, rows = img_of[order], rows[order]
+
+    # ---- candidates, in the reference's order: image, then anchor, then (multi-label) class
+    scores = rows[:, 4:4 + nc]
+    if multi_label:
+        r, c = torch.nonzero(scores > conf_thres, as_tuple=True)
+        conf = scores[r, c]
     else:
-        prediction = torch.cat((xywh2xyxy(prediction[..., :4]), prediction[..., 4:]), dim=-1)
-    output = [torch.zeros((0, 6 + nm), device=prediction.device)] * bs
-    for xi, x in enumerate(prediction):
-        x = x[xc[xi]]
-        if not x.shape[0]:
-            continue
-        box, cls, mask = x.split((4, nc, nm), 1)
-        if multi_label:
-            i, j = torch.where(cls > conf_thres)
-            x = torch.cat((box[i], x[i, 4 + j, None], j[:, None].float(), mask[i]), 1)
-        else:
-            conf, j = cls.max(1, keepdim=True)
-            x = torch.cat((box, conf, j.float(), mask), 1)[conf.view(-1) > conf_thres]
-        if classes is not None:
-            x = x[(x[:, 5:6] == classes).any(1)]
-        n = x.shape[0]
-        if not n:
-            continue
-        if n > max_nms:
-            x = x[x[:, 4].argsort(descending=True)[:max_nms]]
-        c = x[:, 5:6] * (0 if agnostic else max_wh)
-        i = nms(x[:, :4] + c, x[:, 4], iou_thres)
-        output[xi] = x[i[:max_det]]
-    return output
+        conf, c = scores.max(1)
+        r = torch.nonzero(conf > conf_thres, as_tuple=True)[0]
+        conf, c = conf[r], c[r]
+    if wanted is not None:
+        sel = (c.unsqueeze(1) == wanted.view(1, -1)).any(1)
+        r, c, conf = r[sel], c[sel], conf[sel]
+    img = img_of[r]
+
+    # ---- per image: descending score, ties by candidate order (what a stable sort of each image's rows gives; the reference's
+    # `argsort(descending=True)[:max_nms]` followed by nms's own ordering selects and orders the same rows)
+    by_score = torch.sort(conf, descending=True, stable=True).indices
+    by_image = torch.sort(img[by_score], stable=True).indices
+    order = by_score[by_image]
+    r, c, conf, img = r[order], c[order], conf[order], img[order]
+    counts = torch.bincount(img, minlength=B).tolist()         # host read 1 of 2: candidates per image
+    if counts and max(counts) > max_nms:                       # keep each image's max_nms best
+        counts_t = torch.tensor(counts, device=dev)
+        starts = torch.cumsum(counts_t, 0) - counts_t
+        sel = (torch.arange(img.numel(), device=dev) - starts[img]) < max_nms
+        r, c, conf, img = r[sel], c[sel], conf[sel], img[sel]
+        counts = [min(n, max_nms) for n in counts]
+    cls_f = c.to(rows.dtype)
+    box = rows[r, :4]
+    shifted = box if agnostic else box + (cls_f * max_wh).unsqueeze(1)      # classes never overlap: one NMS for all of them
+
+    # ---- greedy suppression per image segment (HIP), then the first max_det survivors of each image
+    keep = torch.zeros(img.numel(), dtype=torch.bool, device=dev)
+    shifted = shifted.contiguous()
+    lo = 0
+    for n in counts:
+        if n:
+            keep[lo:lo + n] = _suppress(shifted[lo:lo + n], conf[lo:lo + n], iou_thres)
+        lo += n
+    kept = torch.nonzero(keep, as_tuple=True)[0]
+    kimg = img[kept]
+    kcount = torch.bincount(kimg, minlength=B)
+    krank = torch.arange(kept.numel(), device=dev) - (torch.cumsum(kcount, 0) - kcount)[kimg]
+    kept = kept[krank < max_det]
+    final = torch.cat((box[kept], conf[kept, None], cls_f[kept, None], rows[r[kept], 4 + nc:]), 1)
+    sizes = torch.bincount(img[kept], minlength=B).tolist()    # host read 2 of 2: survivors per image
+    return list(torch.split(final, sizes))

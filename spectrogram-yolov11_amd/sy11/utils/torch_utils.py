@@ -36,20 +36,46 @@ def initialize_weights(model):
 
 
 def intersect_dicts(da, db, exclude=()):
-    return {k: v for k, v in da.items() if k in db and all(x not in k for x in exclude) and v.shape == db[k].shape}
+    """Entries of ``da`` that ``db`` also has under the same key with the same shape, minus keys containing an ``exclude`` fragment."""
+    common = {}
+    for key, value in da.items():
+        twin = db.get(key)
+        if twin is None or twin.shape != value.shape or any(frag in key for frag in exclude):
+            continue
+        common[key] = value
+    return common
 
 
 def de_parallel(model):
-    return model.module if hasattr(model, "module") and isinstance(model.module, nn.Module) else model
+    """The wrapped module of a DataParallel / DDP container, else the model itself."""
+    inner = getattr(model, "module", None)
+    return inner if isinstance(inner, nn.Module) else model
 
 
 def init_seeds(seed=0, deterministic=False):
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
+    """Seed every generator (torch_utils.py:474-492).  ``deterministic`` (cfg/default.yaml:29) switches libsy11 to ordered
+    reductions and pins the tile choice: see ``set_deterministic``."""
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     if torch.cuda.is_available():
-        torch.cuda.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
+    set_deterministic(bool(deterministic))
+
+
+def set_deterministic(on: bool = True):
+    """The reference's `deterministic: True` (torch.use_deterministic_algorithms, torch_utils.py:483-489) for the HIP path: every sum
+    over workgroups (BatchNorm statistics and backward sums, filter gradients, loss partials, bias gradients) is taken in a fixed
+    order (libsy11 option "deterministic", csrc/det.h), and the tile autotuner stops measuring (the heuristic or an imported pick
+    table decides) — a different tile is a different summation order.  Two runs on the same inputs are then bit-identical; the
+    price is the fold launches and slower filter gradients.  Turning it off restores the measuring tuner only if SY11_TUNE allows."""
+    import os
+
+    from .. import _lib
+    _lib.set_option("deterministic", 1 if on else 0)
+    if on:
+        _lib.set_option("tune", 0)
+    elif os.environ.get("SY11_TUNE", "1") != "0":
+        _lib.set_option("tune", 1)
 
 
 class ModelEMA:
@@ -78,8 +104,11 @@ class ModelEMA:
         torch._foreach_add_(ev, mv, alpha=1 - d)
 
     def update_attr(self, model, include=(), exclude=("process_group", "reducer")):
-        if self.enabled:
-            for k, v in model.__dict__.items():
-                if (len(include) and k not in include) or k.startswith("_") or k in exclude:
-                    continue
-                setattr(self.ema, k, v)
+        """Mirror the model's public plain attributes (names, nc, args, ...) onto the averaged copy."""
+        if not self.enabled:
+            return
+        for name, value in vars(model).items():
+            private = name.startswith("_")
+            if private or name in exclude or (include and name not in include):
+                continue
+            setattr(self.ema, name, value)

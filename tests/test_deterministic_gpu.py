@@ -1,0 +1,109 @@
+"""GPU: the ordered-reduction mode (`deterministic: True`, cfg/default.yaml:29, utils/torch_utils.py:474-492 in the reference;
+libsy11 option "deterministic", csrc/det.h).  Two runs of the same program on the same inputs must be BIT-identical — loss,
+every parameter gradient, the weights after optimizer steps — in f32 and in f16, eagerly and through hipGraph replay, at test size
+and at the bench's size; and the mode must not change what is computed (the default mode agrees to rounding)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle import yolo11_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture()
+def deterministic():
+    from sy11 import _lib
+    from sy11.utils.torch_utils import set_deterministic
+    prev = (_lib.get_option("deterministic"), _lib.get_option("tune"))
+    set_deterministic(True)
+    yield
+    _lib.set_option("deterministic", prev[0])
+    _lib.set_option("tune", prev[1])
+
+
+def _batch(B, sz, nc, seed):
+    g = torch.Generator().manual_seed(seed)
+    n = 3 * B
+    return {"img": torch.rand(B, 3, sz, sz, generator=g).to(DEV), "batch_idx": torch.arange(B).repeat_interleave(3).float().to(DEV),
+            "cls": torch.randint(0, nc, (n, 1), generator=g).float().to(DEV),
+            "bboxes": torch.cat((0.25 + 0.5 * torch.rand(n, 2, generator=g), 0.1 + 0.4 * torch.rand(n, 2, generator=g)), 1).to(DEV)}
+
+
+def _same(a, b):
+    """Bit-for-bit equality (NaN-safe: compares the representation, not the value)."""
+    return a.shape == b.shape and torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32))
+
+
+def _one_step(cfg, layers, nc, dtype, batch, seed=3):
+    from sy11.nn.tasks import DetectionModel
+    torch.manual_seed(seed)
+    m = DetectionModel(cfg, nc=nc, verbose=False)
+    m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    if layers is not None:
+        m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(layers), seed=seed))
+    m._sy11_dtype = dtype
+    m = m.to(DEV).train()
+    loss, items = m(batch)
+    (loss * 64.0).backward()
+    flat = m.__dict__["_sy11_grads"].flat.clone()
+    bn = torch.cat([b.flatten().float() for k, b in m.named_buffers() if "running" in k])
+    return loss.detach().clone(), items.clone(), flat, bn
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
+@pytest.mark.parametrize("model", ["yolo11n", "fusion"])
+def test_two_runs_are_bit_identical(deterministic, dtype, model):
+    if model == "fusion":
+        cfg, layers, nc = "yolo11s_fusion_sand3_new.yaml", R.resolve_graph("s", nc=2, graph=R.GRAPH_FUSION), 2
+    else:
+        cfg, layers, nc = "yolo11n.yaml", R.resolve_graph("n", nc=80), 80
+    batch = _batch(8, 160, nc, seed=1)
+    a = _one_step(cfg, layers, nc, dtype, batch)
+    b = _one_step(cfg, layers, nc, dtype, batch)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (a[0], b[0])
+    assert torch.equal(a[3], b[3]), "BatchNorm running statistics differ between two runs"
+    assert torch.equal(a[2], b[2]), f"{int((a[2] != b[2]).sum())} of {a[2].numel()} gradient elements differ between two runs"
+    assert float(a[2].abs().max()) > 0
+
+
+def test_mode_does_not_change_the_result(deterministic):
+    """Ordered and atomic reductions add the same partial sums: the two modes agree to f32 rounding."""
+    from sy11 import _lib
+    layers = R.resolve_graph("n", nc=80)
+    batch = _batch(8, 160, 80, seed=2)
+    a = _one_step("yolo11n.yaml", layers, 80, torch.float32, batch)
+    _lib.set_option("deterministic", 0)
+    b = _one_step("yolo11n.yaml", layers, 80, torch.float32, batch)
+    assert abs(float(a[0]) - float(b[0])) <= 1e-5 * abs(float(b[0]))
+    assert (a[2] - b[2]).norm().item() <= 1e-4 * b[2].norm().item()
+
+
+@pytest.mark.parametrize("amp", [False, True], ids=["f32", "amp_f16"])
+def test_trainer_steps_with_graph_replay_are_bit_identical(deterministic, amp):
+    """6 trainer steps (2 eager + capture + replays; SGD-nesterov, clip, EMA, GradScaler): weights, EMA and losses of two runs."""
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+
+    def run():
+        m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
+        m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
+        tr = DetectionTrainer(m, batch_size=8, device=DEV, overrides={"amp": amp, "nbs": 8, "warmup_epochs": 0, "deterministic": True}, graphs=True)
+        losses = [tr.train_step(dict(_batch(8, 128, 80, seed=10 + i)))[0].clone() for i in range(6)]
+        return torch.stack(losses), tr.flat.flat.clone(), tr.ema.ema_state.flat.clone(), tr.flat.flat_buf.clone()
+    a, b = run(), run()
+    for x, y, what in zip(a, b, ("losses", "weights", "EMA", "BatchNorm buffers")):
+        assert _same(x, y), f"{what}: {int((x != y).sum())} of {x.numel()} values differ between two runs"
+    assert torch.isfinite(a[0]).all()
+
+
+def test_full_size_step_is_bit_identical(deterministic):
+    """The bench's shape: yolo11s, 64 x 3 x 640 x 640, f16."""
+    batch = _batch(64, 640, 80, seed=5)
+    a = _one_step("yolo11s.yaml", None, 80, torch.float16, batch)            # the constructor's initialisation: a loss the f16 gradients survive
+    b = _one_step("yolo11s.yaml", None, 80, torch.float16, batch)
+    assert torch.isfinite(a[2]).all() and float(a[2].abs().max()) > 0
+    assert _same(a[0], b[0]) and _same(a[3], b[3])
+    assert _same(a[2], b[2]), f"{int((a[2] != b[2]).sum())} of {a[2].numel()} gradient elements differ between two runs"

@@ -28,12 +28,15 @@ HW = [(80, 80), (40, 40), (20, 20)]
 
 @pytest.fixture()
 def tuner_on():
-    """The bench's configuration: first eager call of a problem measures the candidates and keeps the fastest."""
+    """The bench's configuration: first eager call of a problem measures the candidates and keeps the fastest; reductions across
+    workgroups through f32 atomics (the suite's default is the ordered mode, tests/conftest.py)."""
     from sy11 import _lib
-    prev = _lib.get_option("tune")
+    prev = _lib.get_option("tune"), _lib.get_option("deterministic")
     _lib.set_option("tune", 1)
+    _lib.set_option("deterministic", 0)
     yield
-    _lib.set_option("tune", prev)
+    _lib.set_option("tune", prev[0])
+    _lib.set_option("deterministic", prev[1])
 
 
 def _targets(B, nc, per_image, seed):

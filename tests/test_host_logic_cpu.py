@@ -183,9 +183,9 @@ def test_ddp_flat_allreduce_gloo_world2(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
-def test_criterion_host_side_packing_matches_oracle_and_cpu_maps_fail_loudly():
-    """v8DetectionLoss: the target packing (utils/loss.py:194-207) is host-side tensor logic — checked against the oracle on
-    CPU for ragged, empty-image and device-free labels; the criterion itself is HIP only and must refuse CPU maps."""
+def test_criterion_refuses_cpu_tensors_loudly():
+    """v8DetectionLoss is HIP only — criterion AND target packing (sy11_det_loss_pack_targets since r03; its parity test against the
+    oracle's pack_targets is tests/test_loss_gpu.py): CPU tensors must raise, there is no tensor-op detour."""
     from oracle import loss_ref
     from sy11._lib import Sy11Error
     from sy11.utils import tal
@@ -196,15 +196,8 @@ def test_criterion_host_side_packing_matches_oracle_and_cpu_maps_fail_loudly():
                             parameters=lambda: iter([torch.zeros(1)]))
     crit = v8DetectionLoss(model)
     g = torch.Generator().manual_seed(4)
-    for B, ids in ((2, [0, 0, 1]), (4, [3, 0, 3, 3, 1]), (3, [2]), (5, [4, 4, 0, 4, 4, 0, 2])):
-        n = len(ids)
-        bi = torch.tensor(ids, dtype=torch.float32)
-        cls = torch.randint(0, nc, (n, 1), generator=g).float()
-        box = torch.cat((0.2 + 0.6 * torch.rand(n, 2, generator=g), 0.05 + 0.3 * torch.rand(n, 2, generator=g)), 1)
-        scale = torch.tensor([64., 48., 64., 48.])
-        got = crit.preprocess(torch.cat((bi.view(-1, 1), cls, box), 1), B, scale_tensor=scale, batch_idx=bi)
-        ref = loss_ref.pack_targets(bi, cls, box, B, scale)
-        assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-5), (B, ids)
+    with pytest.raises(Sy11Error):
+        crit.preprocess(torch.rand(3, 6), 2, scale_tensor=(64.0, 48.0))
     assert crit.preprocess(torch.zeros(0, 6), 3, scale_tensor=torch.ones(4)).shape == (3, 0, 5)
     maps = [torch.randn(2, 64 + nc, h, h) for h in (8, 4, 2)]
     batch = {"batch_idx": torch.tensor([0., 0., 1.]), "cls": torch.tensor([[1.], [4.], [2.]]),
@@ -226,7 +219,9 @@ def test_criterion_host_side_packing_matches_oracle_and_cpu_maps_fail_loudly():
 
 
 def test_nms_wrapper_candidate_selection_matches_reference_rows(monkeypatch):
-    """non_max_suppression (product) hands the same rows to its NMS core as the reference handed to torchvision."""
+    """non_max_suppression (product, batched) hands the same rows to its suppression core as the reference handed to
+    torchvision.ops.nms — the product passes each image's rows already in (score descending, candidate order) order, i.e. the
+    golden rows under a stable descending sort of their scores."""
     from sy11.utils import ops as uops
     from tests._golden import load
     gold = load("nms_inputs.npz")
@@ -235,15 +230,36 @@ def test_nms_wrapper_candidate_selection_matches_reference_rows(monkeypatch):
 
     def fake(boxes, scores, thr):
         seen.append((boxes.clone(), scores.clone()))
-        return torch.arange(boxes.shape[0])
-    monkeypatch.setattr(uops, "nms", fake)
+        return torch.ones(boxes.shape[0], dtype=torch.bool)
+    monkeypatch.setattr(uops, "_suppress", fake)
     for tag, kw in (("best", dict(conf_thres=0.25, iou_thres=0.7, multi_label=False)),
                     ("multi", dict(conf_thres=0.05, iou_thres=0.7, multi_label=True))):
         seen.clear()
-        uops.non_max_suppression(pred.clone(), max_det=300, **kw)
-        assert len(seen) == int(gold[f"{tag}.n"])
+        out = uops.non_max_suppression(pred.clone(), max_det=300, **kw)
+        assert len(seen) == int(gold[f"{tag}.n"]) and len(out) == pred.shape[0]
         for i, (b, s) in enumerate(seen):
-            assert np.array_equal(b.numpy(), gold[f"{tag}.{i}.boxes"]) and np.array_equal(s.numpy(), gold[f"{tag}.{i}.scores"])
+            gs = torch.from_numpy(gold[f"{tag}.{i}.scores"])
+            order = torch.sort(gs, descending=True, stable=True).indices
+            assert np.array_equal(s.numpy(), gs[order].numpy()) and np.array_equal(b.numpy(), gold[f"{tag}.{i}.boxes"][order.numpy()])
+
+
+def test_nms_wrapper_apriori_labels_and_class_filter_on_cpu(monkeypatch):
+    """ops.py:272-278 (apriori labels appended to an image's candidates) and the `classes` filter, with the suppression core stubbed
+    (keep everything): the label rows come out with score 1.0 and their class, ahead of every prediction of that image."""
+    from sy11.utils import ops as uops
+    monkeypatch.setattr(uops, "_suppress", lambda b, s, t: torch.ones(b.shape[0], dtype=torch.bool))
+    g = torch.Generator().manual_seed(0)
+    pred = torch.rand(2, 4 + 3, 50, generator=g)
+    pred[:, :2] = 20 + 60 * pred[:, :2]
+    pred[:, 2:4] = 5 + 20 * pred[:, 2:4]
+    labels = [torch.tensor([[2.0, 50.0, 50.0, 10.0, 20.0]]), torch.zeros(0, 5)]
+    out = uops.non_max_suppression(pred.clone(), 0.5, 0.6, labels=labels, multi_label=False)
+    assert torch.equal(out[0][0], torch.tensor([45.0, 40.0, 55.0, 60.0, 1.0, 2.0]))        # the label: xyxy box, score 1, class 2
+    plain = uops.non_max_suppression(pred.clone(), 0.5, 0.6, multi_label=False)
+    assert out[0].shape[0] == plain[0].shape[0] + 1 and torch.equal(out[1], plain[1]) and torch.equal(out[0][1:], plain[0])
+    only1 = uops.non_max_suppression(pred.clone(), 0.5, 0.6, classes=[1], multi_label=True)
+    for a, b in zip(only1, uops.non_max_suppression(pred.clone(), 0.5, 0.6, multi_label=True)):
+        assert torch.equal(a, b[b[:, 5] == 1])
 
 
 def test_flat_state_alignment_and_views():

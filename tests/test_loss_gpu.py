@@ -85,3 +85,25 @@ def test_device_labels_with_recycled_addresses_are_repacked_per_batch():
         del dev_batch, feats
     with pytest.raises(Exception):
         crit(80, fused=False)                         # there is no tensor-op criterion in the product
+
+
+def test_target_packing_kernel_matches_oracle_bit_exact():
+    """sy11_det_loss_pack_targets vs the oracle's restated v8DetectionLoss.preprocess (utils/loss.py:194-207): ragged counts,
+    images without targets, a single target, many targets per image (> one 64-lane ballot), host and device labels, strided columns."""
+    c = crit(6)
+    g = torch.Generator().manual_seed(4)
+    cases = [(2, [0, 0, 1]), (4, [3, 0, 3, 3, 1]), (3, [2]), (5, [4, 4, 0, 4, 4, 0, 2]),
+             (64, torch.randint(0, 64, (700,), generator=g).tolist()), (3, [1] * 150 + [0] * 3)]
+    for B, ids in cases:
+        n = len(ids)
+        bi = torch.tensor(ids, dtype=torch.float32)
+        cls = torch.randint(0, 6, (n, 1), generator=g).float()
+        box = torch.cat((0.2 + 0.6 * torch.rand(n, 2, generator=g), 0.05 + 0.3 * torch.rand(n, 2, generator=g)), 1)
+        scale = torch.tensor([64., 48., 64., 48.])
+        ref = loss_ref.pack_targets(bi, cls, box, B, scale)
+        t = torch.cat((bi.view(-1, 1), cls, box), 1)
+        for targets, idx in ((t, bi), (t.to(DEV), bi.to(DEV))):                  # host labels (dataloader) and device labels (bench)
+            got = c.preprocess(targets, B, scale_tensor=(64.0, 48.0), batch_idx=idx)
+            assert got.shape == ref.shape and torch.equal(got.cpu(), ref), (B, n)
+        got = c.preprocess(t, B, scale_tensor=scale.to(DEV), batch_idx=bi)       # the reference's tensor-valued scale
+        assert torch.equal(got.cpu(), ref)

@@ -29,6 +29,7 @@ def main():
     verbose = "-v" in sys.argv
     B, dt, reps = 64, torch.float16, 10
     tot = {m: 0.0 for m in modes}
+    floors = {}
     lines = []
     for (H, W, C, N, k, s, g, cnt) in LAYERS:
         p = k // 2
@@ -61,11 +62,14 @@ def main():
             ms = e0.elapsed_time(e1) / reps
             tot[m] += ms * cnt
             gf = 2.0 * B * OH * OW * N * (C // g) * k * k / 1e9
-            row += f"  {m} {ms * 1e3:7.1f} us {gf / ms:6.0f} TF/s"
+            by = (B * H * W * C + B * OH * OW * N + N * (C // g) * k * k) * 2.0
+            floor = max(by / 5.5e12, gf * 1e9 / 1.6e15) * 1e3          # ms: streaming rate / sustained MFMA rate measured on this part
+            floors[m] = floors.get(m, 0.0) + floor * cnt
+            row += f"  {m} {ms * 1e3:7.1f} us {gf / ms:6.0f} TF/s x{ms / floor:4.1f}"
         lines.append(row)
     if verbose:
         print("\n".join(lines))
-    print("TOTAL ms/step: " + "  ".join(f"{m} {v:.3f}" for m, v in tot.items()))
+    print("TOTAL ms/step: " + "  ".join(f"{m} {v:.3f} (floor {floors[m]:.3f})" for m, v in tot.items()))
 
 
 if __name__ == "__main__":
