@@ -57,12 +57,15 @@ const char* sy11_last_error(void);
  *   "tune_log" 0|1, "igemm_cfg" / "wgrad_cfg" (-1 = automatic, else force one tile configuration), "igemm_korder" 0|1,
  *   "igemm_deep" 0|1|2 (deeper LDS rings), "igemm_bpol" 0|1|2 (cache policy of the filter-row copies),
  *   "dgrad_s2_halo" 0|1 (3x3 stride-2 input gradient: four igemm launches, one per output parity / ONE fused-parity pass),
- *   "row_map" 0|1 (row walk of the BatchNorm and copy kernels: strided grid of r01 / contiguous chunk per workgroup).
+ *   "row_map" 0|1 (row walk of the BatchNorm and copy kernels: strided grid of r01 / contiguous chunk per workgroup),
+ *   "deterministic" 0|1   ordered reductions (cfg/default.yaml:29 `deterministic: True`, utils/torch_utils.py:474-492): every sum
+ *                         across workgroups — BatchNorm statistics and backward sums, filter / bias gradients, loss partials —
+ *                         goes through one partial row per workgroup and a fixed-shape fold instead of f32 atomics; bit-identical
+ *                         results run to run when the tile choice is pinned ("tune" 0 or an imported pick table).  The partial
+ *                         rows live in a per-stream workspace the LIBRARY allocates (grown during eager warm-up, never under capture).
  * Defaults come from the environment (SY11_TUNE, SY11_TUNE_LOG, SY11_IGEMM_CFG, SY11_WGRAD_CFG, SY11_IGEMM_KORDER,
- * SY11_IGEMM_DEEP, SY11_IGEMM_BPOL, SY11_DGRAD_S2_HALO, SY11_ROW_MAP).  Process-wide; set them between launches, not
- * concurrently with them.
- * (There is no "deterministic" switch: sums over pixels use f32 atomics in LDS and in HBM — see DESIGN.md §5 for what an
- * ordered mode would take; cfg/default.yaml:29 `deterministic` is therefore NOT honoured.)                              */
+ * SY11_IGEMM_DEEP, SY11_IGEMM_BPOL, SY11_DGRAD_S2_HALO, SY11_ROW_MAP, SY11_DETERMINISTIC).  Process-wide; set them between
+ * launches, not concurrently with them.                                                                                */
 int sy11_set_option(const char* name, int32_t value);
 int sy11_get_option(const char* name, int32_t* value);
 /* The autotuner's pick tables as a flat array of 16-byte records {u64 problem hash, i32 kind, i32 pick}: export on one
@@ -240,6 +243,12 @@ int sy11_detect_decode(int32_t B, int32_t nc, int32_t nl, const float* const* ma
 int sy11_nms_sorted(int32_t n, const float* boxes, float iou_thres, uint64_t* workspace, uint8_t* keep,
                     void* stream);
 size_t sy11_nms_workspace_bytes(int32_t n);
+/* The same for `nseg` images at once: image i owns counts[i] consecutive rows of boxes / keep (HOST array; rows of an image in
+ * score-descending order).  Images run side by side; each sweep stops after `max_keep` survivors (ops.py:322 keeps at most max_det
+ * rows per image) and clears the rest of its keep flags.  workspace: as many bytes as the ..._workspace_bytes query below returns.  */
+int sy11_nms_sorted_batched(int32_t nseg, const int32_t* counts, const float* boxes, float iou_thres, int32_t max_keep,
+                            uint64_t* workspace, uint8_t* keep, void* stream);
+size_t sy11_nms_batched_workspace_bytes(int32_t nseg, const int32_t* counts);
 
 /* ---- fused detection criterion (v8DetectionLoss.__call__, utils/loss.py:221-275; TaskAlignedAssigner, utils/tal.py:40-296;
  *      bbox_iou CIoU, utils/metrics.py:171-234).  maps: nl NHWC f32 head maps (B, H_l*W_l, 64+nc); gt: (B, G, 5) rows

@@ -158,6 +158,112 @@ extern "C" int sy11_nms_sorted(int32_t n, const float* boxes, float iou_thres, u
   return SY11_OK;
 }
 
+// ---- batched form: up to NMS_SEGS images per launch, each a contiguous run of rows of `boxes` (score-descending inside the run).
+// The per-image work is unchanged (same IoU arithmetic, same greedy order => the same kept set, bit for bit); what changes is that
+// the images run side by side — the greedy sweep is ONE wave per image and latency-bound (a dependent global row read per
+// surviving box), so 64 images in one launch take the time of the slowest instead of the sum — and that the sweep stops after
+// `max_keep` survivors (the callers keep at most max_det rows per image: ops.py:322), the rest of `keep` is cleared.
+#define NMS_SEGS 128
+struct NmsSegs {
+  int start[NMS_SEGS];          // first row of the segment in boxes / keep
+  int n[NMS_SEGS];              // rows
+  long ws[NMS_SEGS];            // first mask word of the segment in the workspace
+  int count;
+};
+__global__ __launch_bounds__(64) void nms_mask_batched_kernel(const NmsSegs sg, const float* __restrict__ boxes_all, float thr, uint64_t* __restrict__ mask_all) {
+#pragma clang fp contract(off)
+  const int seg = blockIdx.z, n = sg.n[seg], nw = (n + 63) >> 6;
+  const int cb = blockIdx.x, rb = blockIdx.y;
+  if (cb >= nw || rb >= nw) return;
+  const float* boxes = boxes_all + (long)sg.start[seg] * 4;
+  uint64_t* mask = mask_all + sg.ws[seg];
+  const int lane = threadIdx.x;
+  const int i = rb * 64 + lane;
+  if (cb < rb) {                                   // left of the diagonal: j <= i never suppressed by i; written, so no memset pass is needed
+    if (i < n) mask[(long)i * nw + cb] = 0;
+    return;
+  }
+  __shared__ float cbx[64][4];
+  const int cj = cb * 64 + lane;
+  if (cj < n) { cbx[lane][0] = boxes[cj * 4]; cbx[lane][1] = boxes[cj * 4 + 1]; cbx[lane][2] = boxes[cj * 4 + 2]; cbx[lane][3] = boxes[cj * 4 + 3]; }
+  __syncthreads();
+  if (i >= n) return;
+  const float x1 = boxes[i * 4], y1 = boxes[i * 4 + 1], x2 = boxes[i * 4 + 2], y2 = boxes[i * 4 + 3];
+  const float ai = (x2 - x1) * (y2 - y1);
+  uint64_t bits = 0;
+  const int jmax = min(64, n - cb * 64);
+  for (int j = 0; j < jmax; ++j) {
+    const int gj = cb * 64 + j;
+    if (gj <= i) continue;
+    const float xx1 = fmaxf(x1, cbx[j][0]), yy1 = fmaxf(y1, cbx[j][1]);
+    const float xx2 = fminf(x2, cbx[j][2]), yy2 = fminf(y2, cbx[j][3]);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float aj = (cbx[j][2] - cbx[j][0]) * (cbx[j][3] - cbx[j][1]);
+    const float iou = inter / (ai + aj - inter);
+    if (iou > thr) bits |= (1ull << j);
+  }
+  mask[(long)i * nw + cb] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_sweep_batched_kernel(const NmsSegs sg, const uint64_t* __restrict__ mask_all, uint8_t* __restrict__ keep_all, int max_keep) {
+  extern __shared__ uint64_t removed[];
+  const int seg = blockIdx.x, n = sg.n[seg], nw = (n + 63) >> 6;
+  const uint64_t* mask = mask_all + sg.ws[seg];
+  uint8_t* keep = keep_all + sg.start[seg];
+  const int lane = threadIdx.x;
+  for (int w = lane; w < nw; w += 64) removed[w] = 0;
+  __syncthreads();
+  int kept = 0, i = 0;
+  for (; i < n && kept < max_keep; ++i) {
+    const uint64_t r = removed[i >> 6];            // wave-uniform read
+    const bool dead = (r >> (i & 63)) & 1;
+    if (lane == 0) keep[i] = dead ? 0 : 1;
+    if (!dead) {
+      ++kept;
+      const uint64_t* row = mask + (long)i * nw;
+      for (int w = (i >> 6) + lane; w < nw; w += 64) removed[w] |= row[w];
+    }
+    __syncthreads();
+  }
+  for (int j = i + lane; j < n; j += 64) keep[j] = 0;            // past the max_keep-th survivor: never reported
+}
+
+extern "C" size_t sy11_nms_batched_workspace_bytes(int32_t nseg, const int32_t* counts) {
+  size_t words = 0;
+  for (int i = 0; i < nseg; ++i) words += counts[i] > 0 ? (size_t)counts[i] * ((counts[i] + 63) / 64) : 0;
+  return words * sizeof(uint64_t);
+}
+
+extern "C" int sy11_nms_sorted_batched(int32_t nseg, const int32_t* counts, const float* boxes, float iou_thres, int32_t max_keep, uint64_t* workspace,
+                                       uint8_t* keep, void* stream) {
+  SY11_REQUIRE(nseg >= 0 && (nseg == 0 || counts), "nms_sorted_batched: bad segment list");
+  SY11_REQUIRE(max_keep > 0, "nms_sorted_batched: max_keep must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  long row = 0, word = 0;
+  for (int s0 = 0; s0 < nseg; s0 += NMS_SEGS) {
+    NmsSegs sg{};
+    int max_nw = 0;
+    for (int s = s0; s < nseg && s < s0 + NMS_SEGS; ++s) {
+      const int n = counts[s];
+      SY11_REQUIRE(n >= 0 && n <= 65535 * 64, "nms_sorted_batched: segment %d has %d rows", s, n);
+      const int nw = (n + 63) / 64;
+      SY11_REQUIRE((size_t)nw * 8 <= 64 * 1024, "nms_sorted_batched: n=%d exceeds the LDS removed-mask", n);
+      sg.start[sg.count] = (int)row; sg.n[sg.count] = n; sg.ws[sg.count] = word;
+      row += n; word += (long)n * nw;
+      SY11_REQUIRE(row < (1L << 31), "nms_sorted_batched: too many rows");
+      if (nw > max_nw) max_nw = nw;
+      ++sg.count;
+    }
+    if (max_nw == 0) continue;
+    SY11_REQUIRE(boxes && workspace && keep, "nms_sorted_batched: null pointer");
+    hipLaunchKernelGGL(nms_mask_batched_kernel, dim3(max_nw, max_nw, sg.count), dim3(64), 0, st, sg, boxes, iou_thres, workspace);
+    hipLaunchKernelGGL(nms_sweep_batched_kernel, dim3(sg.count), dim3(64), (size_t)max_nw * 8, st, sg, (const uint64_t*)workspace, keep, max_keep);
+  }
+  SY11_LAUNCH_CHECK("nms_sorted_batched");
+  return SY11_OK;
+}
+
 
 // ------------------------------------------------------------------------------------------------ pairwise IoU
 // box_iou of the validator (utils/metrics.py:52-72): out[i][j] = inter / (area_a[i] + area_b[j] - inter + eps), every

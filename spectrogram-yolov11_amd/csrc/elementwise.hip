@@ -389,7 +389,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const 
     for (int e = threadIdx.x; e < l.nch; e += 256) {
       const int ch = l.cbase + e;
       float tg = 0.f, tgx = 0.f;
-      for (int k = 0; k < slots; ++k) { tg += sum_g[(long)k * C + ch]; tgx += sum_gx[(long)k * C + ch]; }
+      // eight slots' loads in flight at a time (a `for k < slots` loop waits for every pair before issuing the next: on the
+      // 20x20 / 40x40 maps those 8 dependent round trips were most of a workgroup's life); summed in slot order
+      for (int k0 = 0; k0 < slots; k0 += 8) {
+        float a8[8], b8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + j < slots ? k0 + j : slots - 1;
+          a8[j] = sum_g[(long)k * C + ch];
+          b8[j] = sum_gx[(long)k * C + ch];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k0 + j < slots) { tg += a8[j]; tgx += b8[j]; }
+      }
       if (blockIdx.x == 0 && dgamma) { atomicAdd(dgamma + ch, tgx); atomicAdd(dbeta + ch, tg); }
       const float rs = rstd[ch], gr = gamma[ch] * rs;
       s_sc[e] = scale[ch];
@@ -437,7 +450,13 @@ extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const 
   const int esz = dtype_size(dtype);
   const bool v = vec_ok(esz, C, {y_ld, dz_ld, dy_ld}, {y, dz, dy});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
-  const RowWalk w = row_walk(M, g.rows_pb, 4, 2, 1L << 20);          // the slot fold of the prologue is paid per block: two trips
+  // the slot fold of the prologue is paid per block (C x slots x 2 loads): two trips per block on the big maps; on small maps with
+  // many channels (20x20x512: the fold reads as many bytes as a two-trip block streams) four or eight
+  static int trips_env = -1;
+  if (trips_env < 0) { const char* e = getenv("SY11_BN_APPLY_TRIPS"); trips_env = e ? atoi(e) : 0; }
+  int trips = (C >= 512 && M <= 65536) ? 4 : 2;      // r03 sweep (graph replay, us): 20x20x512 26.1 / 18.9 / 17.4 / 19.0 at 2 / 3 / 4 / 8 trips;
+  if (trips_env > 0) trips = trips_env;              // 20x20x256 10.1 / 11.4 / 10.7 / 15.5, 40x40x256 and larger: flat or worse
+  const RowWalk w = row_walk(M, g.rows_pb, 4, trips, 1L << 20);
   dim3 grid(w.grid, g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   SY11_DISPATCH_DTYPE(dtype, T, {

@@ -81,6 +81,7 @@ SIGNATURES = {
     "sy11_attention_bwd": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
     "sy11_detect_decode": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_nms_sorted": [_i32, _vp, _f32, _vp, _vp, _vp],
+    "sy11_nms_sorted_batched": [_i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp],
     "sy11_det_loss_assign": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_det_loss_terms": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "sy11_det_loss_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp],
@@ -106,6 +107,7 @@ SIGNATURES.update({
 })
 OTHER = {"sy11_version": ([], C.c_int), "sy11_last_error": ([], C.c_char_p),
          "sy11_nms_workspace_bytes": ([_i32], C.c_size_t),
+         "sy11_nms_batched_workspace_bytes": ([_i32, _vp], C.c_size_t),
          "sy11_attention_workspace_bytes": ([_i32, _i32, _i32], C.c_size_t),
          "sy11_tune_export": ([_vp, _i64], C.c_int64)}
 

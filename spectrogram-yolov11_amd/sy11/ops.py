@@ -317,6 +317,36 @@ def nms_sorted(boxes_sorted: torch.Tensor, iou_thres: float) -> torch.Tensor:
     return keep.bool()
 
 
+def nms_sorted_batched(boxes_sorted: torch.Tensor, counts, iou_thres: float, max_keep: int, chunk_bytes: int = 2 << 30) -> torch.Tensor:
+    """Greedy NMS of several images in one go: image i owns counts[i] consecutive rows of ``boxes_sorted`` ((total, 4) f32, each
+    image's rows in score-descending order).  -> bool keep mask (total,), at most ``max_keep`` survivors per image.  The bit
+    matrices of a launch are bounded by ``chunk_bytes`` (images are processed in as many launches as that takes)."""
+    _need_gpu(boxes_sorted)
+    total = boxes_sorted.shape[0]
+    keep = torch.empty((total,), dtype=torch.uint8, device=boxes_sorted.device)
+    if total == 0:
+        return keep.bool()
+    b = boxes_sorted.contiguous().float()
+    lib = _lib.load()
+    counts = [int(c) for c in counts]
+    need = [c * ((c + 63) // 64) * 8 for c in counts]
+    lo, row = 0, 0
+    while lo < len(counts):
+        hi, size = lo, 0
+        while hi < len(counts) and (hi == lo or size + need[hi] <= chunk_bytes):
+            size += need[hi]
+            hi += 1
+        n_rows = sum(counts[lo:hi])
+        if n_rows:
+            arr = (C.c_int32 * (hi - lo))(*counts[lo:hi])
+            ws = torch.empty((max(size // 8, 1),), dtype=torch.int64, device=b.device)
+            call("sy11_nms_sorted_batched", hi - lo, C.cast(arr, C.c_void_p), _p(b[row:row + n_rows]), float(iou_thres), int(max_keep), _p(ws),
+                 _p(keep[row:row + n_rows]), _stream())
+        row += n_rows
+        lo = hi
+    return keep.bool()
+
+
 def stft_logmel(iq, window, mel_start, mel_w, n_fft, hop, n_frames, n_mel):
     """iq: (B, L) complex64 -> (db (B, frames, n_mel) f32, minmax (B, 2) f32)."""
     _need_gpu(iq, window, mel_start, mel_w)

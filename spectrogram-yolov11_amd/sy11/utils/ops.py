@@ -3,8 +3,8 @@ non_max_suppression :181-332, clip_boxes :335-354, xyxy2xywh :412-429, xywh2xyxy
 
 ``non_max_suppression`` is re-cut for the device: candidate selection, class offsets, the per-image score ordering and the
 `max_nms` / `max_det` truncations are done ONCE for the whole batch with tensor ops (one host read of the per-image candidate
-counts instead of a Python loop with several reads per image); only the greedy suppression itself runs per image, on the HIP
-bit-matrix kernel (``sy11_nms_sorted``) that stands where the reference calls ``torchvision.ops.nms`` (ops.py:312), fed in
+counts instead of a Python loop with several reads per image); the greedy suppression itself runs for all images side by side on the HIP
+bit-matrix kernels (``sy11_nms_sorted_batched``) that stands where the reference calls ``torchvision.ops.nms`` (ops.py:312), fed in
 (score descending, index ascending) order so the kept set is bit-exact.  The reference's wall-clock break (ops.py:328-330) is
 intentionally absent: results never depend on time.
 """
@@ -75,11 +75,12 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
     return order[keep]
 
 
-def _suppress(boxes_sorted, scores_sorted, iou_threshold):
-    """Greedy suppression of ONE image's candidates, already in (score descending, candidate order) order -> bool keep mask.
+def _suppress(boxes_sorted, scores_sorted, counts, iou_threshold, max_keep):
+    """Greedy suppression of a batch: image i owns counts[i] consecutive rows, already in (score descending, candidate order) order
+    -> bool keep mask with at most ``max_keep`` survivors per image (ONE launch pair for all images: sy11_nms_sorted_batched).
     (``scores_sorted`` is not needed by the kernel: the order carries it.  Kept in the signature for the parity tests, which
     intercept this call to compare the rows with what the reference hands to torchvision.ops.nms.)"""
-    return _k.nms_sorted(boxes_sorted, float(iou_threshold))
+    return _k.nms_sorted_batched(boxes_sorted, counts, float(iou_threshold), int(max_keep))
 
 
 def _prior_rows(labels, nc, nm, dtype, device):
@@ -167,19 +168,13 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     box = rows[r, :4]
     shifted = box if agnostic else box + (cls_f * max_wh).unsqueeze(1)      # classes never overlap: one NMS for all of them
 
-    # ---- greedy suppression per image segment (HIP), then the first max_det survivors of each image
-    keep = torch.zeros(img.numel(), dtype=torch.bool, device=dev)
-    shifted = shifted.contiguous()
-    lo = 0
-    for n in counts:
-        if n:
-            keep[lo:lo + n] = _suppress(shifted[lo:lo + n], conf[lo:lo + n], iou_thres)
-        lo += n
+    # ---- greedy suppression, all images side by side (HIP), then the first max_det survivors of each image
+    keep = _suppress(shifted.contiguous(), conf, counts, iou_thres, max_det)
     kept = torch.nonzero(keep, as_tuple=True)[0]
     kimg = img[kept]
     kcount = torch.bincount(kimg, minlength=B)
     krank = torch.arange(kept.numel(), device=dev) - (torch.cumsum(kcount, 0) - kcount)[kimg]
-    kept = kept[krank < max_det]
+    kept = kept[krank < max_det]                               # (the kernel already stops at max_det survivors; a stub may not)
     final = torch.cat((box[kept], conf[kept, None], cls_f[kept, None], rows[r[kept], 4 + nc:]), 1)
     sizes = torch.bincount(img[kept], minlength=B).tolist()    # host read 2 of 2: survivors per image
     return list(torch.split(final, sizes))

@@ -228,8 +228,12 @@ def test_nms_wrapper_candidate_selection_matches_reference_rows(monkeypatch):
     pred = torch.from_numpy(gold["pred"])
     seen = []
 
-    def fake(boxes, scores, thr):
-        seen.append((boxes.clone(), scores.clone()))
+    def fake(boxes, scores, counts, thr, max_keep):
+        lo = 0
+        for n in counts:                                              # one record per image with candidates, as the reference calls nms
+            if n:
+                seen.append((boxes[lo:lo + n].clone(), scores[lo:lo + n].clone()))
+            lo += n
         return torch.ones(boxes.shape[0], dtype=torch.bool)
     monkeypatch.setattr(uops, "_suppress", fake)
     for tag, kw in (("best", dict(conf_thres=0.25, iou_thres=0.7, multi_label=False)),
@@ -247,7 +251,7 @@ def test_nms_wrapper_apriori_labels_and_class_filter_on_cpu(monkeypatch):
     """ops.py:272-278 (apriori labels appended to an image's candidates) and the `classes` filter, with the suppression core stubbed
     (keep everything): the label rows come out with score 1.0 and their class, ahead of every prediction of that image."""
     from sy11.utils import ops as uops
-    monkeypatch.setattr(uops, "_suppress", lambda b, s, t: torch.ones(b.shape[0], dtype=torch.bool))
+    monkeypatch.setattr(uops, "_suppress", lambda b, s, c, t, k: torch.ones(b.shape[0], dtype=torch.bool))
     g = torch.Generator().manual_seed(0)
     pred = torch.rand(2, 4 + 3, 50, generator=g)
     pred[:, :2] = 20 + 60 * pred[:, :2]

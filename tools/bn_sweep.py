@@ -63,7 +63,9 @@ def sweep(eager):
         dy = torch.empty_like(y)
         f = lambda *sh: torch.rand(*sh, device="cuda") + 0.5
         mean, rstd, scale, shift, gamma = f(N), f(N), f(N), f(N), f(N)
-        sg, sgx = torch.zeros(8, N, device="cuda"), torch.zeros(8, N, device="cuda")      # 8 slots, as nn/modules/conv.py
+        import os
+        ns = int(os.environ.get("BN_SLOTS", "8"))
+        sg, sgx = torch.zeros(ns, N, device="cuda"), torch.zeros(ns, N, device="cuda")      # 8 slots, as nn/modules/conv.py
         dgam, dbet = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
         fns = {"fwd": (lambda: ops.bn_act_fwd(y, scale, shift, z, True), 2),
                "reduce": (lambda: ops.bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, True, sg, sgx), 2),
