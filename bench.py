@@ -316,6 +316,7 @@ def main():
     ap.add_argument("--no-fwd-leg", action="store_true", help="skip the forward-only (configs[1]) leg reported next to the headline")
     ap.add_argument("--no-extras", action="store_true", help="skip the f32 train line and the configs[4] model line")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel individually instead of hipGraph replay")
+    ap.add_argument("--leg", default="", choices=["", "predict_val"], help="run ONE reporting leg only and print its JSON (for rocprofv3 profiles of that leg)")
     a = ap.parse_args()
 
     from sy11 import _lib
@@ -344,6 +345,28 @@ def main():
         else:
             data = {"img": torch.rand(a.batch, 3, a.imgsz, a.imgsz, device=dev)}
         return tr, data, labels
+
+    if a.leg == "predict_val":                              # the predict / val side alone: fused eval forward + decode + batched NMS
+        from sy11.engine import enable_graphs
+        m = DetectionModel(a.model, nc=a.nc, verbose=False).to(dev).eval()
+        m._sy11_dtype = torch.float16 if a.dtype == "f16" else torch.float32
+        m.fuse()
+        enable_graphs(m)
+        img = torch.rand(a.batch, 3, a.imgsz, a.imgsz, device=dev)
+        with torch.no_grad():
+            for _ in range(max(a.warmup, 3)):
+                m(img)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                m(img)
+            torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t0) / a.steps * 1e3
+        leg = predict_val_leg(m, img, a.batch, a.nc, a.steps)
+        leg["fused_eval_forward_ms"] = round(fwd_ms, 3)
+        leg["val_images_per_s_forward_plus_nms"] = round(a.batch / ((fwd_ms + leg["nms"]["wrapper_ms_per_batch"]) * 1e-3), 1)
+        print(json.dumps(leg))
+        return
 
     tr, data, labels = make(a.model, a.nc, a.dtype, not a.no_stft, world)
 

@@ -58,7 +58,22 @@ with open(dst / "pmc_hbm_traffic_by_kernel.csv", "w", newline="") as f:
     w.writerow(["kernel", "launches_per_step", "FETCH_SIZE_KiB_sum", "WRITE_SIZE_KiB_sum", "corrected_bytes_per_launch", "corrected_GB_per_step"])
     for b, k, v in rows[:100]:
         w.writerow([k[:160], round(v["n"] / steps, 2), round(v["FETCH_SIZE"], 1), round(v["WRITE_SIZE"], 1), round(b / max(v["n"], 1)), round(b / steps / 1e9, 3)])
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes): python3 bench.py --steps 2 --warmup 3 --no-graphs "
+import subprocess  # noqa: E402
+
+
+def _git(*args):
+    try:
+        return subprocess.run(["git", *args], capture_output=True, text=True, cwd=Path(__file__).resolve().parents[1]).stdout.strip()
+    except Exception:
+        return ""
+
+
+out = {"commit": _git("rev-parse", "HEAD"), "worktree_dirty": bool(_git("status", "--porcelain", "--", "spectrogram-yolov11_amd", "bench.py")),
+       "commands": ["SY11_TUNE_SAVE=$OUT/picks.bin python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-fwd-leg --no-extras",
+                    "SY11_TUNE_LOAD=$OUT/picks.bin SY11_TUNE=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/FETCH_SIZE -o run -- python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-fwd-leg --no-extras --no-graphs",
+                    "SY11_TUNE_LOAD=$OUT/picks.bin SY11_TUNE=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/WRITE_SIZE -o run -- python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-fwd-leg --no-extras --no-graphs",
+                    f"python tools/pmc_summary.py {src} {dst} {steps}"],
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes): python3 bench.py --steps 2 --warmup 3 --no-graphs "
                  "--no-cpu-baseline --no-roofline --no-fwd-leg --no-extras; last steps only; FETCH x2 (gfx950), WRITE x1",
        "steps_profiled": steps, "total_GB_per_step": round(total / steps / 1e9, 3),
        "families": {k: {"launches_per_step": round(v["n"] / steps, 2), "GB_per_step": round(v["bytes"] / steps / 1e9, 4),
