@@ -16,6 +16,7 @@ import torch
 
 from .. import ops as K
 from ..utils.instance import Instances
+from .recipe import LazyImage, is_lazy, letterbox_image
 
 
 def _to_device_u8(img, device):
@@ -139,6 +140,8 @@ class LetterBox:
         H, W = new_unpad[1] + top + bottom, new_unpad[0] + left + right
         if (H, W) == shape and shape[::-1] == new_unpad:
             out = src                                               # nothing to resize, nothing to pad
+        elif is_lazy(src):                                          # loader worker process: record the step, no pixels here
+            out = letterbox_image(src, (H, W), (new_unpad[1], new_unpad[0]), top, left, 114)
         else:
             out = torch.empty((H, W, 3), dtype=torch.uint8, device=src.device)
             K.image_letterbox(src, out, (new_unpad[1], new_unpad[0]), top, left, 114, reverse_c=False, chw=False)
@@ -249,7 +252,9 @@ class DeviceImage:
         if isinstance(img, DeviceImage):
             return img
         was_numpy = isinstance(img, np.ndarray)
-        if was_numpy:
+        if is_lazy(img):
+            t = img
+        elif was_numpy:
             if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
                 raise ValueError(f"expected an (h, w, 3) uint8 image, got {img.dtype} {img.shape}")
             t = torch.from_numpy(np.ascontiguousarray(img))
@@ -284,6 +289,25 @@ class DeviceImage:
                 return t
         return None
 
+    # -- loader worker processes (data/recipe.py): tiles may be LazyImage nodes — shapes without pixels
+    def has_lazy(self):
+        return any(is_lazy(t[0]) for t in self.tiles)
+
+    def frozen(self):
+        """A detached copy of the recipe (what a "render" LazyImage node carries)."""
+        c = DeviceImage(list(self.tiles), self.canvas_hw, self.fill)
+        c.minv, c.out_hw, c.lut, c.flip_ud, c.flip_lr = self.minv, self.out_hw, self.lut, self.flip_ud, self.flip_lr
+        c.was_numpy, c.final_reverse_c = self.was_numpy, self.final_reverse_c
+        return c
+
+    def resolved(self, materialize):
+        """The same recipe with every LazyImage tile turned into a device tensor (training process)."""
+        if not self.has_lazy():
+            return self
+        c = self.frozen()
+        c.tiles = [(materialize(t[0]), *t[1:]) for t in self.tiles]
+        return c
+
     # -- recipe edits
     def _flatten(self):
         t = self.render(chw=False)
@@ -317,6 +341,11 @@ class DeviceImage:
             plain = self.plain_tensor()
             if plain is not None and not chw and not reverse_c and dtype == torch.uint8:
                 return plain
+        if self.has_lazy():
+            if dst is None and not chw and not reverse_c and dtype == torch.uint8:
+                return LazyImage((H, W), ("render", self.frozen()))          # a worker asked for intermediate pixels: defer them too
+            raise RuntimeError("DeviceImage.render: the recipe still holds LazyImage tiles — resolve() it in the training process first")
+        if dst is None:
             dst = torch.empty((3, H, W) if chw else (H, W, 3), dtype=dtype, device=self.device)
         K.image_mosaic_warp(self.tiles, self.canvas_hw, dst, minv=self.minv, hsv_lut=self.lut, flip_ud=self.flip_ud,
                             flip_lr=self.flip_lr, fill=self.fill, reverse_c=reverse_c, chw=chw)

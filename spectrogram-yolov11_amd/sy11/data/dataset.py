@@ -9,8 +9,10 @@ of verify_image_label :100-165), cut for the MI355X:
     augmentation chain of a sample is ONE launch that writes into that sample's slot of the batch tensor
     (``collate_fn`` allocates the batch, or fills a caller-provided static input, and renders the deferred images).
 
-Because the samples hold device tensors the loader runs in the training process (no worker processes to pickle
-through); file decoding for the next batch overlaps through a small thread pool."""
+Two loaders share this dataset: ``InfiniteDataLoader`` runs everything in the training process (file decoding for the next batch
+overlaps through a small thread pool); ``WorkerLoader`` moves the per-sample Python — random draws, label geometry, recipe
+building — into worker PROCESSES that never touch the GPU and ship ~1.5 KB recipes (data/recipe.py), the reference's
+DataLoader(num_workers=...) re-cut for pixels that live in HBM."""
 from __future__ import annotations
 
 import glob
@@ -27,6 +29,7 @@ import torch
 from .. import ops as K
 from ..utils.instance import Instances
 from .augment import Compose, DeviceImage, Format, LetterBox, v8_transforms
+from .recipe import Materializer, file_image, is_lazy, letterbox_image
 
 IMG_FORMATS = {"bmp", "dng", "jpeg", "jpg", "mpo", "png", "tif", "tiff", "webp", "pfm", "heic", "npy"}   # data/utils.py:38 + raw .npy
 # cfg/default.yaml augmentation block
@@ -132,7 +135,15 @@ class YOLODataset:
         self.max_buffer_length = min((self.ni, self.batch_size * 8, 1000)) if self.augment else 0
         self.ims, self.im_hw0, self.im_hw = [None] * self.ni, [None] * self.ni, [None] * self.ni
         self._decoding = {}                                                 # index -> Future of a background read_image
+        self.recipe_mode = False                                            # True inside a loader worker process: images are LazyImage nodes
         self.transforms = self.build_transforms(hyp=self.hyp)
+
+    def __getstate__(self):
+        """What a worker process receives: files, labels, hyper-parameters, transforms — no pixels, no futures."""
+        st = dict(self.__dict__)
+        st["ims"], st["im_hw0"], st["im_hw"] = [None] * self.ni, [None] * self.ni, [None] * self.ni
+        st["_decoding"], st["buffer"] = {}, []
+        return st
 
     # -- files and labels
     def get_img_files(self, img_path):
@@ -206,19 +217,24 @@ class YOLODataset:
         """base.py:151-187: decode, long side -> imgsz (cv2.resize INTER_LINEAR semantics, on the GPU), mosaic buffer."""
         im = self.ims[i]
         if im is None:
-            fut = self._decoding.pop(i, None)
-            src = fut.result() if fut is not None else self._decode_upload(i)
+            if self.recipe_mode:                                            # worker process: the shape is all the transforms need
+                src = file_image(i, self.labels[i]["shape"])
+            else:
+                fut = self._decoding.pop(i, None)
+                src = fut.result() if fut is not None else self._decode_upload(i)
             h0, w0 = src.shape[:2]
             if rect_mode:
                 r = self.imgsz / max(h0, w0)
                 size = (min(math.ceil(h0 * r), self.imgsz), min(math.ceil(w0 * r), self.imgsz)) if r != 1 else (h0, w0)
             else:
                 size = (self.imgsz, self.imgsz)
-            if size != (h0, w0):
+            if size == (h0, w0):
+                im = src
+            elif is_lazy(src):
+                im = letterbox_image(src, size, size, 0, 0, 114)
+            else:
                 im = torch.empty((*size, 3), dtype=torch.uint8, device=src.device)
                 K.image_letterbox(src, im, size, 0, 0, 114, reverse_c=False, chw=False)
-            else:
-                im = src
             if self.augment:
                 self.ims[i], self.im_hw0[i], self.im_hw[i] = im, (h0, w0), tuple(im.shape[:2])
                 self.buffer.append(i)
@@ -274,7 +290,7 @@ class YOLODataset:
 
     # -- batches
     @staticmethod
-    def collate_fn(batch, out=None, dtype=torch.uint8):
+    def collate_fn(batch, out=None, dtype=torch.uint8, materialize=None):
         """dataset.py:231-248, plus the rendering of deferred images: every sample's recipe is executed by one launch
         straight into slot b of the batch tensor (``out`` — e.g. a captured graph's static input — or a new one; a
         float dtype also folds preprocess_batch's /255 into the same pass)."""
@@ -295,6 +311,8 @@ class YOLODataset:
                     else:
                         imgs = torch.empty((len(value), 3, H, W), dtype=dtype, device=value[0].device)
                     for b, v in enumerate(value):
+                        if materialize is not None:                     # recipes from worker processes: source nodes -> HBM tensors
+                            v = v.resolved(materialize)
                         v.render(dst=imgs[b], chw=True, reverse_c=v.final_reverse_c)
                     value = imgs
                 else:
@@ -392,7 +410,161 @@ def seed_worker(worker_id=0):
     random.seed(worker_seed)
 
 
-def build_dataloader(dataset, batch, workers=8, shuffle=True, rank=-1, world_size=1, out=None, dtype=torch.uint8):
-    """data/build.py:129-157 (workers = decode threads here)."""
-    return InfiniteDataLoader(dataset, batch, shuffle=shuffle, rank=rank, world_size=world_size, prefetch=min(workers, os.cpu_count() or 1),
-                              out=out, dtype=dtype)
+def _worker_main(payload, wid, seed, tasks, results):
+    """Body of a loader worker process: never touches the GPU.  Receives (generation, batch id, indices) tasks, answers with
+    (generation, batch id, [sample dicts with DeviceImage recipes]); ("close_mosaic", hyp) and None (exit) are control messages."""
+    import pickle
+    ds = pickle.loads(payload)
+    ds.recipe_mode = True
+    random.seed(seed + wid)                                   # data/build.py:89-93 seed_worker: a stream of its own per worker
+    np.random.seed((seed + wid) % 2**32)
+    torch.manual_seed(seed + wid)
+    while True:
+        msg = tasks.get()
+        if msg is None:
+            return
+        if msg[0] == "close_mosaic":
+            ds.close_mosaic(msg[1])
+            continue
+        gen, bid, indices = msg
+        try:
+            results.put((gen, bid, [ds[i] for i in indices], None))
+        except Exception as e:                                # noqa: BLE001 — reported to the training process, which raises
+            import traceback
+            results.put((gen, bid, None, f"{e!r}\n{traceback.format_exc()}"))
+
+
+class WorkerLoader(InfiniteDataLoader):
+    """InfiniteDataLoader whose per-sample Python runs in ``procs`` worker processes (data/build.py:129-157 `workers`).
+
+    Batch k goes to worker k % procs (the reference's DataLoader order); up to 2 x procs batches are in flight.  A worker returns
+    recipes over LazyImage nodes (data/recipe.py); as soon as a batch's recipes arrive the training process starts decoding /
+    uploading the source files it names (thread pool, GIL released), so by the time the batch is due its pixels are in HBM and
+    collate_fn renders every sample with one launch.  Each worker owns a copy of the dataset (its own mosaic buffer and random
+    streams, seeded seed + worker id), so — as in the reference — the samples depend on the number of workers."""
+
+    def __init__(self, dataset, batch_size, procs, shuffle=True, rank=-1, world_size=1, seed=0, prefetch=4, out=None, dtype=torch.uint8):
+        super().__init__(dataset, batch_size, shuffle=shuffle, rank=rank, world_size=world_size, seed=seed, prefetch=max(prefetch, 2), out=out, dtype=dtype)
+        import multiprocessing as mp
+        import pickle
+        ctx = mp.get_context("spawn")                         # fresh interpreters: nothing of this process's GPU state is inherited
+        payload = pickle.dumps(dataset)
+        self.procs = max(int(procs), 1)
+        self.results = ctx.Queue()
+        self.tasks = [ctx.Queue() for _ in range(self.procs)]
+        self.workers = [ctx.Process(target=_worker_main, args=(payload, w, 1000003 * (seed + 1) + 7919 * max(rank, 0), self.tasks[w], self.results), daemon=True)
+                        for w in range(self.procs)]
+        for p in self.workers:
+            p.start()
+        self.generation = 0
+        self.materialize = Materializer(self._fetch, dataset.device)
+        self._closed = False
+        prev = getattr(dataset, "close_mosaic")
+
+        def close_everywhere(hyp):                            # dataset.py:197-202, in this process and in every worker
+            prev(hyp)
+            for q in self.tasks:
+                q.put(("close_mosaic", hyp))
+            self.reset()
+        dataset.close_mosaic = close_everywhere
+
+    # -- source pixels
+    def _fetch(self, index):
+        fut = self.dataset._decoding.pop(index, None)
+        return fut.result() if fut is not None else self.dataset._decode_upload(index)
+
+    def _sources(self, node, acc):
+        if is_lazy(node):
+            if node.op[0] == "file":
+                acc.add(node.op[1])
+            elif node.op[0] == "letterbox":
+                if node.key() not in self.materialize.cache:
+                    self._sources(node.op[1], acc)
+            elif node.op[0] == "render":
+                for t in node.op[1].tiles:
+                    self._sources(t[0], acc)
+
+    def _start_decodes(self, samples):
+        need = set()
+        for smp in samples:
+            img = smp.get("img")
+            if isinstance(img, DeviceImage):
+                for t in img.tiles:
+                    self._sources(t[0], need)
+        ds = self.dataset
+        for i in need:
+            if ("file", i) not in self.materialize.cache and i not in ds._decoding and self.pool is not None:
+                ds._decoding[i] = self.pool.submit(ds._decode_upload, i)
+
+    # -- batches
+    def _forever(self):
+        depth = 2 * self.procs
+        gen = self.generation
+        pending, ready = [], {}
+        next_id = 0
+
+        def batches():
+            while True:
+                idx = self._epoch_indices()
+                for i in range(0, len(idx), self.batch_size):
+                    yield idx[i:i + self.batch_size]
+                self.epoch += 1
+        stream = batches()
+        while True:
+            while len(pending) < depth:                       # keep the workers `depth` batches ahead
+                b = next(stream)
+                self.tasks[next_id % self.procs].put((gen, next_id, b))
+                pending.append(next_id)
+                next_id += 1
+            want = pending[0]
+            while want not in ready:
+                g, bid, samples, err = self.results.get()
+                if g != gen:
+                    continue                                  # a batch prepared before reset(): discarded
+                if err is not None:
+                    raise RuntimeError(f"loader worker failed on batch {bid}: {err}")
+                self._start_decodes(samples)
+                ready[bid] = samples
+            samples = ready.pop(pending.pop(0))
+            out = self.out(len(samples)) if callable(self.out) else self.out
+            yield self.dataset.collate_fn(samples, out=out, dtype=self.dtype, materialize=self.materialize)
+
+    def reset(self):
+        self.generation += 1
+        self._it = self._forever()
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        for q in self.tasks:
+            try:
+                q.put(None)
+            except Exception:                                  # noqa: BLE001
+                pass
+        for p in self.workers:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.kill()                                       # exact PIDs of processes this object started
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                      # noqa: BLE001
+            pass
+
+
+def build_dataloader(dataset, batch, workers=8, shuffle=True, rank=-1, world_size=1, out=None, dtype=torch.uint8, procs=None):
+    """data/build.py:129-157.  ``workers``: as in the reference, the loader's parallelism.  Training datasets (augment, no rect) get
+    min(workers, CPUs - 1, 8) recipe WORKER PROCESSES (``WorkerLoader``) plus as many decode threads; validation / rect datasets and
+    workers <= 1 stay in-process (``InfiniteDataLoader``: decode threads only).  ``procs`` (or SY11_LOADER_PROCS) overrides the count,
+    0 = in-process."""
+    ncpu = os.cpu_count() or 1
+    threads = max(min(workers, ncpu), 0)
+    if procs is None:
+        env = os.environ.get("SY11_LOADER_PROCS")
+        procs = int(env) if env is not None else (min(workers, max(ncpu - 1, 1), 8) if workers > 1 else 0)
+    usable = dataset.augment and not dataset.rect and all("shape" in lb for lb in dataset.labels[:1])
+    if procs > 0 and usable:
+        return WorkerLoader(dataset, batch, procs, shuffle=shuffle, rank=rank, world_size=world_size, prefetch=max(threads, 2), out=out, dtype=dtype)
+    return InfiniteDataLoader(dataset, batch, shuffle=shuffle, rank=rank, world_size=world_size, prefetch=threads, out=out, dtype=dtype)
