@@ -1067,6 +1067,322 @@ __global__ __launch_bounds__(256) void stem_wgrad_mma(const StemArgs a, float* d
   }
 }
 
+// ---- LDS-tiled MFMA stem (r03; strides 1 and 2).  The gather kernels above spend their time on ADDRESSES: 27 scalar f32 gathers
+// per pixel, each with clamped coordinates and a validity bit (stem_fwd_mma 274 us, stem_wgrad_mma 390 us for 64 x 3 x 640 x 640
+// against 133 us of image + output bytes).  Here a workgroup owns a 4 x 64 block of output pixels of one image: the image rows under
+// the block (<= 9 x 132 x 3 values) are read ONCE with aligned 16-byte loads, rounded to the MFMA type and laid out as
+// [channel][row][column] in LDS with the zero padding already in place; an operand slot is then one ds_read_u16 at
+// (lane's pixel offset + the slot's constant offset) — no coordinates, no masks.  Values and MFMA order are those of the gather
+// kernels: results are bit-identical.
+constexpr int STILE_H = 4, STILE_W = 64, STILE_RH = 9, STILE_RWP = 136, STILE_IT = 4;     // IT: 16-byte groups per thread per tile
+
+// launch constants of the tiling (host: stem_tiling): the 16-byte groups per tile row and multiply-shift reciprocals for the
+// per-thread group index and the (scalar) tile index
+struct StemTiling { int tiles_x, tiles_y, tiles, RH, shift, NV; unsigned mag_nv, mag_tx, mag_ty; };
+
+struct StemTile { int b, oy0, ox0; };
+__device__ __forceinline__ StemTile stem_tile_at(int t, const StemTiling& g) {
+  StemTile ti;                                         // workgroup-uniform: s_mul_hi_u32 instead of three emulated divisions
+  const int q = g.tiles_x == 1 ? t : (int)__umulhi((unsigned)t, g.mag_tx), tx = t - q * g.tiles_x;      // (2^32 / 1 does not fit)
+  ti.b = g.tiles_y == 1 ? q : (int)__umulhi((unsigned)q, g.mag_ty);
+  ti.oy0 = (q - ti.b * g.tiles_y) * STILE_H;
+  ti.ox0 = tx * STILE_W;
+  return ti;
+}
+
+// a thread's share of the image rows under tile `ti` (global -> registers; zeros outside the image), and registers -> LDS as
+// [channel][row][column] 16-bit patterns of T.  Group `id` = (channel, row, 16-byte group v); the tile's first column sits at
+// element `shift` of its LDS row.  VEC (IW % 4 == 0, 16-byte aligned image): a group is wholly inside or wholly outside the
+// image row, so it is ONE unconditional 16-byte load from a clamped address plus a select — no branches, all loads in flight.
+struct StemRows { float f[STILE_IT][4]; };
+template <bool VEC>
+__device__ __forceinline__ void stem_rows_load(const StemArgs& a, const StemTiling& g, const StemTile& ti, StemRows& r) {
+  const int gy0 = ti.oy0 * a.SH - a.PH, gxa = ti.ox0 * a.SW - a.PW - g.shift;
+  const int plane = a.IH * a.IW;                       // B * 3 * plane < 2^31 (host)
+  const float* xb = a.x + (long)ti.b * 3 * plane;
+#pragma unroll
+  for (int it = 0; it < STILE_IT; ++it) {
+    const int id = threadIdx.x + 256 * it;
+    const int rc = (int)(((unsigned)id * g.mag_nv) >> 16), v = id - rc * g.NV;
+    const int c = (rc >= g.RH) + (rc >= 2 * g.RH), ry = rc - c * g.RH;
+    const int gy = gy0 + ry, gx = gxa + 4 * v;
+    const bool rowin = rc < 3 * g.RH && (unsigned)gy < (unsigned)a.IH;
+    const int cc = min(c, 2), cy = min(max(gy, 0), a.IH - 1);
+    const float* row = xb + cc * plane + cy * a.IW;
+    if (VEC) {
+      const bool in = rowin && gx >= 0 && gx < a.IW;
+      const float4 q4 = *(const float4*)(row + min(max(gx, 0), a.IW - 4));
+      r.f[it][0] = in ? q4.x : 0.f; r.f[it][1] = in ? q4.y : 0.f; r.f[it][2] = in ? q4.z : 0.f; r.f[it][3] = in ? q4.w : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float q1 = row[min(max(gx + i, 0), a.IW - 1)];
+        r.f[it][i] = (rowin && (unsigned)(gx + i) < (unsigned)a.IW) ? q1 : 0.f;
+      }
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void stem_rows_store(const StemTiling& g, const StemRows& r, short* xt) {
+  typedef short s4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int it = 0; it < STILE_IT; ++it) {
+    const int id = threadIdx.x + 256 * it;
+    const int rc = (int)(((unsigned)id * g.mag_nv) >> 16), v = id - rc * g.NV;
+    if (rc < 3 * g.RH)
+      *(s4*)(xt + rc * STILE_RWP + 4 * v) = s4{StemMma<T>::bits(r.f[it][0]), StemMma<T>::bits(r.f[it][1]), StemMma<T>::bits(r.f[it][2]),
+                                               StemMma<T>::bits(r.f[it][3])};
+  }
+}
+
+// element offset of reduction slot k = (r*3+s)*3 + c inside the tile (0 for the padding slots 27..31: masked by the caller)
+__device__ __forceinline__ int stem_tile_slot(int k, int RH) {
+  if (k >= 27) return 0;
+  const int rs = k / 3, c = k - rs * 3, r = rs / 3, s_ = rs - r * 3;
+  return (c * RH + r) * STILE_RWP + s_;
+}
+
+// Persistent: workgroup w takes tiles w, w + gridDim.x, ...; the image rows of the NEXT tile are in flight (registers) while the
+// current one is multiplied, the filter fragments and the statistics live in registers for the whole launch.  The MFMA computes
+// the TRANSPOSED tile (A = filter: rows = output channels, B = patches: columns = pixels), so a lane ends up with 4 x 4
+// consecutive channels of one pixel: the tile goes to the staging buffer in 8-byte writes (r03 first cut, pixels in registers:
+// 32 two-byte LDS writes per lane and tile, a quarter of the kernel), and the per-channel statistics are per-register partial sums
+// that are folded across lanes once per launch.
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(256) void stem_fwd_tile(const StemArgs a, const BnTailDev tail, const StemTiling g) {
+  constexpr int N = 32 * NT, ROWB = N * 2, ROWS = ROWB + 16, CP = ROWB / 16;
+  __shared__ float red[4][2][N];
+  __shared__ __attribute__((aligned(16))) unsigned char stage[256 * ROWS];
+  __shared__ __attribute__((aligned(16))) short xt[3 * STILE_RH * STILE_RWP];      // the image tile as 16-bit patterns of T
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  ss16x8 wf[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 8 * half + 16 * gg + i;
+        wf[nt][gg][i] = k < 27 ? StemMma<T>::bits(ElemTraits<T>::to_f(((const T*)a.w)[(nt * 32 + col) * 27 + k])) : (short)0;
+      }
+  int toff[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) toff[j] = stem_tile_slot(8 * half + 16 * (j >> 3) + (j & 7), g.RH);
+  // slots 27..31 = elements 3..7 of the second fragment of the upper lane half: cleared with three ANDs on the packed words
+  const unsigned keep_lo = half ? 0x0000ffffu : 0xffffffffu, keep_hi = half ? 0u : 0xffffffffu;
+  const bool silu = a.flags & SY11_EPI_SILU;
+  const bool plain = !silu && !a.bias;
+  float s1[NT][16], s2[NT][16], bias_v[NT][16];      // lane: pixel `col`; register e: channel (e&3) + 8*(e>>2) + 4*half (+ 32 nt)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s1[nt][e] = s2[nt][e] = 0.f;
+      bias_v[nt][e] = a.bias ? a.bias[nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half] : 0.f;
+    }
+  StemRows rows;
+  int t = blockIdx.x;
+  StemTile ti = stem_tile_at(min(t, g.tiles - 1), g);
+  if (t < g.tiles) stem_rows_load<VEC>(a, g, ti, rows);
+  for (; t < g.tiles; t += gridDim.x) {
+    __syncthreads();                                  // previous tile: xt read, stage drained
+    stem_rows_store<T>(g, rows, xt);
+    const StemTile cur = ti;
+    if (t + (int)gridDim.x < g.tiles) {
+      ti = stem_tile_at(t + gridDim.x, g);
+      stem_rows_load<VEC>(a, g, ti, rows);
+    }
+    __syncthreads();
+    const bool row_ok = cur.oy0 + wave < a.OH;
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const int oxl = gq * 32 + col;
+      const bool ok = row_ok && cur.ox0 + oxl < a.OW;
+      const short* px = xt + wave * a.SH * STILE_RWP + g.shift + oxl * a.SW;
+      ss16x8 af[2];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) af[j >> 3][j & 7] = px[toff[j]];
+      typedef unsigned u4v __attribute__((ext_vector_type(4)));
+      u4v a0 = __builtin_bit_cast(u4v, af[0]), a1 = __builtin_bit_cast(u4v, af[1]);
+      a1[1] &= keep_lo; a1[2] &= keep_hi; a1[3] &= keep_hi;
+      if (!ok) { a0 = u4v{0, 0, 0, 0}; a1 = u4v{0, 0, 0, 0}; }
+      af[0] = __builtin_bit_cast(ss16x8, a0);
+      af[1] = __builtin_bit_cast(ss16x8, a1);
+      unsigned char* srow = stage + (wave * 64 + oxl) * ROWS + half * 8;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        acc = StemMma<T>::run(wf[nt][0], af[0], acc);
+        acc = StemMma<T>::run(wf[nt][1], af[1], acc);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          typedef T t4 __attribute__((ext_vector_type(4)));
+          t4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = e4 * 4 + i;
+            const float v0 = acc[e];
+            s1[nt][e] += v0;
+            s2[nt][e] += v0 * v0;
+            float v = v0;
+            if (!plain) {
+              v += bias_v[nt][e];
+              if (silu) v = silu_f(v);
+            }
+            o[i] = ElemTraits<T>::from_f(v);
+          }
+          *(t4*)(srow + nt * 64 + e4 * 16) = o;       // channels nt*32 + 8*e4 + 4*half + (0..3)
+        }
+      }
+    }
+    __syncthreads();
+    unsigned char* yimg = (unsigned char*)a.y + (long)cur.b * a.OH * a.OW * ROWB;
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      const int id = i * 256 + tid;
+      const int p = id / CP, cc = id - p * CP;
+      const int oy = cur.oy0 + (p >> 6), ox = cur.ox0 + (p & 63);
+      if (oy < a.OH && ox < a.OW) *(uint4*)(yimg + ((long)oy * a.OW + ox) * ROWB + cc * 16) = *(const uint4*)(stage + p * ROWS + cc * 16);
+    }
+  }
+  if (a.stat_sum) {
+    // fold the 32 pixel lanes of each half (a fixed butterfly), lane 0 / 32 then hold the wave's sums of their 16 channels per nt
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float u1 = s1[nt][e], u2 = s2[nt][e];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) { u1 += __shfl_xor(u1, m); u2 += __shfl_xor(u2, m); }
+        if (col == 0) {
+          const int ch = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          red[wave][0][ch] = u1;
+          red[wave][1][ch] = u2;
+        }
+      }
+    __syncthreads();
+    if (tid < N) {
+      const long so = (long)(blockIdx.x % a.stat_slots) * N;
+      atomicAdd(a.stat_sum + so + tid, ((red[0][0][tid] + red[1][0][tid]) + red[2][0][tid]) + red[3][0][tid]);
+      atomicAdd(a.stat_sq + so + tid, ((red[0][1][tid] + red[1][1][tid]) + red[2][1][tid]) + red[3][1][tid]);
+    }
+    if (tail.ticket) bn_tail_run(tail, a.stat_sum, a.stat_sq, a.stat_slots, N, gridDim.x);
+  }
+}
+
+// dW[n][k] += sum_p dy[p][n] * patch[p][k] over tiles blockIdx.x, + gridDim.x, ...: A = dy^T through the transposing LDS read
+// (each wave stages the dy rows of ITS 32 pixels: wave-private, no workgroup barrier), B = reduction column k = lane out of the
+// tile.  The next tile's image rows and dy rows are in flight while the current tile is multiplied.
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(256) void stem_wgrad_tile(const StemArgs a, float* dw, long part_stride, const StemTiling g) {
+  constexpr int N = 32 * NT, ROW = (N * 2) % 256 == 64 ? N * 2 : N * 2 + 64, CPR = N / 8, DU = (32 * CPR) / 64;
+  __shared__ __attribute__((aligned(16))) unsigned char sdy[4 * 32 * ROW];
+  __shared__ float sacc[NT][32][33];
+  __shared__ __attribute__((aligned(16))) short xt[3 * STILE_RH * STILE_RWP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  for (int i = tid; i < NT * 32 * 33; i += 256) ((float*)sacc)[i] = 0.f;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+  unsigned char* my = sdy + wave * 32 * ROW;
+  const int trq = (lane & 15) >> 2, trp = lane & 3, trg = (lane >> 4) & 1;
+  const int tr_off = (8 * half + trq) * ROW + (trg * 16 + trp * 4) * 2;
+  const T* dyg = (const T*)a.y;                       // a.y carries dy, a.y_ld its pixel stride
+  const bool kcol = col < 27;
+  const short* pk = xt + wave * a.SH * STILE_RWP + g.shift + stem_tile_slot(col, g.RH);
+  StemRows rows;
+  uint4 dv[2][DU];
+  auto dy_load = [&](const StemTile& ti) {
+    const int oy = ti.oy0 + wave;
+    const long mrow = ((long)ti.b * a.OH + min(oy, a.OH - 1)) * a.OW;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const int i = lane + 64 * u, pr = i / CPR, ch = i - pr * CPR;
+        const int ox = ti.ox0 + sub * 32 + pr;
+        const uint4 q4 = *(const uint4*)(dyg + (mrow + min(ox, a.OW - 1)) * a.y_ld + ch * 8);     // clamped, then selected
+        dv[sub][u] = (oy < a.OH && ox < a.OW) ? q4 : make_uint4(0, 0, 0, 0);
+      }
+  };
+  int t = blockIdx.x;
+  StemTile ti = stem_tile_at(min(t, g.tiles - 1), g);
+  if (t < g.tiles) { stem_rows_load<VEC>(a, g, ti, rows); dy_load(ti); }
+  for (; t < g.tiles; t += gridDim.x) {
+    __syncthreads();                                  // every wave is done with the previous tile
+    stem_rows_store<T>(g, rows, xt);
+    uint4 dc[2][DU];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int u = 0; u < DU; ++u) dc[sub][u] = dv[sub][u];
+    if (t + (int)gridDim.x < g.tiles) {
+      ti = stem_tile_at(t + gridDim.x, g);
+      stem_rows_load<VEC>(a, g, ti, rows);
+      dy_load(ti);
+    }
+    __syncthreads();                                  // tile complete
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const int i = lane + 64 * u, pr = i / CPR, ch = i - pr * CPR;
+        *(uint4*)(my + pr * ROW + ch * 16) = dc[sub][u];
+      }
+      ss16x8 bf[2];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bf[j >> 3][j & 7] = pk[(sub * 32 + 8 * half + 16 * (j >> 3) + (j & 7)) * a.SW];
+      if (!kcol) { bf[0] = ss16x8{0, 0, 0, 0, 0, 0, 0, 0}; bf[1] = bf[0]; }
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const unsigned char* pa = my + 16 * gg * ROW + tr_off + nt * 64;
+          const as16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) as16x4_t*)pa);
+          const as16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) as16x4_t*)(pa + 4 * ROW));
+          const ss16x8 af = ss16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          acc[nt] = StemMma<T>::run(af, bf[gg], acc[nt]);
+        }
+    }
+  }
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {                         // the four waves add their tiles one after the other: a fixed order
+    if (wave == w) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[nt][(e & 3) + 8 * (e >> 2) + 4 * half][col] += acc[nt][e];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < N * 27; i += 256) {
+    const int n = i / 27, k = i - n * 27;
+    atomicAdd(dw + (long)blockIdx.x * part_stride + i, sacc[n >> 5][n & 31][k]);
+  }
+}
+
+// tiling of a launch; false: strides other than 1 / 2 or shapes outside the reciprocals' exact range (the gather kernels take those)
+static bool stem_tiling(const sy11_conv_desc* d, StemTiling* g) {
+  if (d->SH < 1 || d->SH > 2 || d->SW < 1 || d->SW > 2 || d->PW < 0 || d->PW > 3 || d->IW < 4) return false;
+  g->tiles_x = (d->OW + STILE_W - 1) / STILE_W;
+  g->tiles_y = (d->OH + STILE_H - 1) / STILE_H;
+  const long tiles = (long)d->B * g->tiles_y * g->tiles_x;
+  // q = umulhi(t, ceil(2^32 / d)) is exact while t * d < 2^32
+  if (tiles * g->tiles_x >= (1L << 31) || tiles * g->tiles_y >= (1L << 31)) return false;
+  g->tiles = (int)tiles;
+  g->mag_tx = (unsigned)(((1UL << 32) + g->tiles_x - 1) / g->tiles_x);     // (a divisor of 1 is special-cased in stem_tile_at)
+  g->mag_ty = (unsigned)(((1UL << 32) + g->tiles_y - 1) / g->tiles_y);
+  g->RH = (STILE_H - 1) * d->SH + 3;
+  g->shift = (-d->PW) & 3;                             // tile origins are multiples of 64 * SW columns: one shift for all tiles
+  g->NV = (g->shift + (STILE_W - 1) * d->SW + 3 + 3) >> 2;
+  g->mag_nv = (65536u + g->NV - 1) / g->NV;            // exact quotients for id < 1024 (checked for NV <= 39)
+  return 3 * g->RH * g->NV <= 256 * STILE_IT;
+}
+
 static int stem_check(const sy11_conv_desc* d, const char* who) {
   SY11_REQUIRE(d && dtype_ok(d->dtype), "%s: bad desc", who);
   SY11_REQUIRE(d->C == 3 && d->KH == 3 && d->KW == 3 && d->DH == 1 && d->DW == 1 && d->groups == 1, "%s: stem kernel is 3x3, Cin=3, dilation 1", who);
@@ -1106,6 +1422,16 @@ static int stem_fwd_tail(const sy11_conv_desc* d, const float* x_nchw, const voi
   const long M = (long)d->B * d->OH * d->OW;
   dim3 grid((unsigned)((M + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  const bool mma = d->dtype != SY11_F32 && (d->N == 32 || d->N == 64) && d->y_ld == d->N && ((uintptr_t)y & 15) == 0 &&
+                   (long)d->B * 3 * d->IH * d->IW < (1L << 31) && (long)(d->OW + 64) * d->OW < (1L << 20) && (long)(d->OH + 64) * d->OH < (1L << 20);
+  static int tile_env = -1, tile_wg = 0;
+  if (tile_env < 0) {
+    const char* e = getenv("SY11_STEM_TILE"); tile_env = e ? atoi(e) : 1;
+    const char* w = getenv("SY11_STEM_FWD_WG"); tile_wg = w ? atoi(w) : 1024;      // persistent workgroups (4 per CU)
+  }
+  StemTiling tg{};
+  const bool tiled = mma && tile_env && stem_tiling(d, &tg);
+  if (tiled) grid = dim3((unsigned)(tg.tiles < tile_wg ? tg.tiles : tile_wg));
   DetPartials dp;                                             // ordered mode (det.h): one partial statistics row per workgroup
   const bool det = stat_sum && sy11_det(2) && !tail.ticket;
   if (det) {
@@ -1113,14 +1439,21 @@ static int stem_fwd_tail(const sy11_conv_desc* d, const float* x_nchw, const voi
     a.stat_sum = dp.buf(0); a.stat_sq = dp.buf(1); a.stat_slots = (int)grid.x;
   }
   auto det_end = [&]() -> int { const int r = dp.fold(0, stat_sum); return r ? r : dp.fold(1, stat_sq); };
-  if (d->dtype != SY11_F32 && (d->N == 32 || d->N == 64) && d->y_ld == d->N && ((uintptr_t)y & 15) == 0 &&
-      (long)d->B * 3 * d->IH * d->IW < (1L << 31) && (long)(d->OW + 64) * d->OW < (1L << 20) && (long)(d->OH + 64) * d->OH < (1L << 20)) {
+  if (mma) {
     a.mag_ow = (unsigned)(((1u << 20) + d->OW - 1) / d->OW);
     a.mag_oh = (unsigned)(((1u << 20) + d->OH - 1) / d->OH);
-    SY11_DISPATCH_DTYPE(d->dtype, T, {
-      if (d->N == 32) hipLaunchKernelGGL((stem_fwd_mma<T, 1>), grid, block, 0, st, a, tail);
-      else hipLaunchKernelGGL((stem_fwd_mma<T, 2>), grid, block, 0, st, a, tail);
-    });
+    if (tiled) {
+      SY11_DISPATCH_DTYPE(d->dtype, T, {
+        const bool vec = (d->IW & 3) == 0 && ((uintptr_t)x_nchw & 15) == 0;
+        if (d->N == 32) { if (vec) hipLaunchKernelGGL((stem_fwd_tile<T, 1, true>), grid, block, 0, st, a, tail, tg); else hipLaunchKernelGGL((stem_fwd_tile<T, 1, false>), grid, block, 0, st, a, tail, tg); }
+        else { if (vec) hipLaunchKernelGGL((stem_fwd_tile<T, 2, true>), grid, block, 0, st, a, tail, tg); else hipLaunchKernelGGL((stem_fwd_tile<T, 2, false>), grid, block, 0, st, a, tail, tg); }
+      });
+    } else {
+      SY11_DISPATCH_DTYPE(d->dtype, T, {
+        if (d->N == 32) hipLaunchKernelGGL((stem_fwd_mma<T, 1>), grid, block, 0, st, a, tail);
+        else hipLaunchKernelGGL((stem_fwd_mma<T, 2>), grid, block, 0, st, a, tail);
+      });
+    }
     SY11_LAUNCH_CHECK("stem_conv_fwd");
     *tail_done = tail.ticket != nullptr && stat_sum != nullptr;
     return det ? det_end() : SY11_OK;
@@ -1156,6 +1489,18 @@ extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw
     if (nb > 512) nb = 512;
     const int ppbm = (int)(((M + nb - 1) / nb + 127) / 128 * 128);
     dim3 gm((unsigned)((M + ppbm - 1) / ppbm));
+    static int tile_env = -1, tile_wg = 0;
+    if (tile_env < 0) {
+      const char* e = getenv("SY11_STEM_TILE"); tile_env = e ? atoi(e) : 1;
+      const char* g = getenv("SY11_STEM_WGRAD_WG"); tile_wg = g ? atoi(g) : 512;
+    }
+    StemTiling tg{};
+    const bool tiled = tile_env && stem_tiling(d, &tg);
+    if (tiled) {                                        // >= 8 tiles (2048 pixels) per workgroup, at most `tile_wg` workgroups
+      long nbt = (tg.tiles + 7) / 8;
+      if (nbt > tile_wg) nbt = tile_wg;
+      gm = dim3((unsigned)nbt);
+    }
     DetPartials dp;                                           // ordered mode (det.h): one partial dW row per workgroup
     float* dwk = dw;
     long pstride = 0;
@@ -1163,10 +1508,18 @@ extern "C" int sy11_stem_conv_wgrad(const sy11_conv_desc* d, const float* x_nchw
       if (!dp.acquire(st, 1, gm.x, d->N * 27)) SY11_FAIL(SY11_ELAUNCH, "stem_conv_wgrad: ordered-reduction workspace unavailable");
       dwk = dp.buf(0); pstride = d->N * 27;
     }
-    SY11_DISPATCH_DTYPE(d->dtype, T, {
-      if (d->N == 32) hipLaunchKernelGGL((stem_wgrad_mma<T, 1>), gm, block, 0, st, am, dwk, ppbm, pstride);
-      else hipLaunchKernelGGL((stem_wgrad_mma<T, 2>), gm, block, 0, st, am, dwk, ppbm, pstride);
-    });
+    if (tiled) {
+      SY11_DISPATCH_DTYPE(d->dtype, T, {
+        const bool vec = (d->IW & 3) == 0 && ((uintptr_t)x_nchw & 15) == 0;
+        if (d->N == 32) { if (vec) hipLaunchKernelGGL((stem_wgrad_tile<T, 1, true>), gm, block, 0, st, am, dwk, pstride, tg); else hipLaunchKernelGGL((stem_wgrad_tile<T, 1, false>), gm, block, 0, st, am, dwk, pstride, tg); }
+        else { if (vec) hipLaunchKernelGGL((stem_wgrad_tile<T, 2, true>), gm, block, 0, st, am, dwk, pstride, tg); else hipLaunchKernelGGL((stem_wgrad_tile<T, 2, false>), gm, block, 0, st, am, dwk, pstride, tg); }
+      });
+    } else {
+      SY11_DISPATCH_DTYPE(d->dtype, T, {
+        if (d->N == 32) hipLaunchKernelGGL((stem_wgrad_mma<T, 1>), gm, block, 0, st, am, dwk, ppbm, pstride);
+        else hipLaunchKernelGGL((stem_wgrad_mma<T, 2>), gm, block, 0, st, am, dwk, ppbm, pstride);
+      });
+    }
     SY11_LAUNCH_CHECK("stem_conv_wgrad");
     return dp.base ? dp.fold(0, dw) : SY11_OK;
   }

@@ -233,6 +233,37 @@ def test_depthwise_conv(Cn, H, W, dtype):
           "dw wgrad", mult=8)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,B,H,W,s,p", [(32, 3, 37, 264, 2, 1), (64, 2, 26, 300, 2, 1), (32, 2, 19, 150, 1, 1), (64, 1, 9, 131, 1, 0),
+                                         (32, 2, 64, 512, 2, 1), (32, 1, 11, 13, 2, 0)])
+def test_stem_conv_lds_tiles(N, B, H, W, s, p, dtype):
+    """The LDS-tiled stem kernels (direct.hip stem_fwd_tile / stem_wgrad_tile: 4 x 64 output pixels per workgroup) on maps several
+    tiles wide and high, ragged last tiles, widths that are not multiples of 4 (scalar fill), both strides, with and without
+    padding — forward, the BatchNorm statistics and the filter gradient against fp32 autograd on the rounded operands."""
+    o = ops()
+    x = (rnd(B, 3, H, W, seed=31) + 1) / 2
+    w = rnd(N, 3, 3, 3, seed=32, scale=0.3)
+    wq, xq = q(w, dtype), q(x, dtype)
+    OH, OW = o.conv_out_hw(H, W, 3, s, p)
+    wk = wq.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    y = torch.full((B, OH, OW, N), float("nan"), dtype=dtype, device=DEV)
+    ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    o.stem_conv_fwd(x.to(DEV), wk, y, s, p, stats=(ssum, ssq))
+    ref = F.conv2d(xq, wq, None, s, p)
+    close(to_nchw(y), ref, dtype, "stem fwd")
+    close(ssum.cpu(), ref.sum((0, 2, 3)), dtype, "stem sum", mult=4)
+    close(ssq.cpu(), (ref * ref).sum((0, 2, 3)), dtype, "stem sumsq", mult=4)
+    dy = rnd(B, N, OH, OW, seed=33)
+    dw = torch.zeros(N, 3, 3, 3, dtype=torch.float32, device=DEV)
+    o.stem_conv_wgrad(x.to(DEV), nhwc(dy, dtype), dw, s, p)
+    close(dw.cpu().permute(0, 3, 1, 2), torch.nn.grad.conv2d_weight(xq, (N, 3, 3, 3), q(dy, dtype), s, p), torch.float32,
+          "stem wgrad", mult=8)
+    dw2 = torch.zeros_like(dw)                                 # accumulates, and twice the same
+    o.stem_conv_wgrad(x.to(DEV), nhwc(dy, dtype), dw2, s, p)
+    o.stem_conv_wgrad(x.to(DEV), nhwc(dy, dtype), dw2, s, p)
+    assert torch.allclose(dw2, 2 * dw, rtol=1e-4, atol=1e-4 * float(dw.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("N,H,W", [(16, 16, 16), (32, 21, 18), (32, 70, 66), (64, 40, 36)])
 def test_stem_conv(N, H, W, dtype):
