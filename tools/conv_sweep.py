@@ -1,11 +1,13 @@
 """Time every distinct convolution of yolo11s (640x640, batch 64, f16) through the C-ABI, per direction, and print the
-multiplicity-weighted totals.  Used to tune tile / split heuristics:  python tools/conv_sweep.py [fwd,fused,dgrad,wgrad] [-v]
+multiplicity-weighted totals.  Used to tune tile / split heuristics:  python tools/conv_sweep.py [fwd,fused,dgrad,wgrad] [-v] [--eager]
+Timed inside a replayed hipGraph of 10 calls, as the trainer runs them (--eager: plain calls, host call rate included).
 
 Layer table = (IH, IW, C, N, k, s, groups, count) of the model graph (count = how many layers share the shape)."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "spectrogram-yolov11_amd"))
+sys.path.insert(0, str(ROOT / "tools"))
 import torch
 from sy11 import ops
 
@@ -26,7 +28,8 @@ LAYERS = [(320, 320, 32, 64, 3, 2, 1, 1), (160, 160, 64, 64, 1, 1, 1, 1), (160, 
 
 def main():
     modes = sys.argv[1].split(",") if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else ["fwd", "dgrad", "wgrad"]
-    verbose = "-v" in sys.argv
+    from bn_sweep import timed                     # 10 calls inside a replayed hipGraph (a small kernel's eager time is the host's call rate)
+    verbose, eager = "-v" in sys.argv, "--eager" in sys.argv
     B, dt, reps = 64, torch.float16, 10
     tot = {m: 0.0 for m in modes}
     floors = {}
@@ -49,17 +52,7 @@ def main():
                "wgrad": lambda: ops.conv2d_wgrad(x, dy, dw, k, s, p, groups=g)}
         row = f"{H:3d}x{W:<3d} {C:4d}->{N:<4d} k{k} s{s} g{g:<3d} x{cnt}"
         for m in modes:
-            f = fns[m]
-            for _ in range(2):
-                f()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                f()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
+            ms = timed(fns[m], reps, eager)
             tot[m] += ms * cnt
             gf = 2.0 * B * OH * OW * N * (C // g) * k * k / 1e9
             by = (B * H * W * C + B * OH * OW * N + N * (C // g) * k * k) * 2.0
