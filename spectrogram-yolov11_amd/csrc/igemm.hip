@@ -241,30 +241,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   auto consume = [&](const unsigned char* st) {
     constexpr int G = CPRW / 2;
     if constexpr (BM == 256) {
-      // 2 waves per SIMD only: software-pipeline the fragment reads one k-group ahead of the MFMAs (two register sets)
-      uint4 fa[2][MI], fb[2][NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[0][i] = *(const uint4*)(st + fa_off[i][0]);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) fb[0][j] = *(const uint4*)(st + fb_off[j][0]);
+      // 1-2 waves per SIMD: nothing else hides an LDS round trip, so ALL fragment reads of the stage are issued before the first
+      // MFMA (G x (MI + NI) x 16 bytes per lane) and the MFMAs drain them in order behind counted waits.  (r02 read one k-group
+      // ahead with two register sets; the register allocator folded the sets into one and the second k-group ran as
+      // read - wait - 4 MFMAs - read - wait ...: three exposed LDS latencies per stage, r03 ISA inspection.)
+      uint4 fa[G][MI], fb[G][NI];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const int cur = g & 1, nxt = cur ^ 1;
-        if (g + 1 < G) {
 #pragma unroll
-          for (int i = 0; i < MI; ++i) fa[nxt][i] = *(const uint4*)(st + fa_off[i][g + 1]);
+        for (int i = 0; i < MI; ++i) fa[g][i] = *(const uint4*)(st + fa_off[i][g]);
 #pragma unroll
-          for (int j = 0; j < NI; ++j) fb[nxt][j] = *(const uint4*)(st + fb_off[j][g + 1]);
-        }
+        for (int j = 0; j < NI; ++j) fb[g][j] = *(const uint4*)(st + fb_off[j][g]);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j) Mma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
-        // pin the order the source states (the machine scheduler otherwise sinks the reads next to their uses to save
-        // registers): all LDS reads of the next group first, then this group's MFMAs
-        if (g + 1 < G) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
-      }
+          for (int j = 0; j < NI; ++j) Mma<T>::run(fa[g][i], fb[g][j], acc[i][j]);
+      // pin the order the source states: the reads first, then the MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, G * (MI + NI), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, G * MI * NI, 0);
     } else {
 #pragma unroll
       for (int g = 0; g < G; ++g) {

@@ -127,6 +127,8 @@ CFG_CASES = [
     (1, 64, 80, 80, 40, 3, 2),       # stride 2 -> 40x40 (3 x 40 tiles over an 81-column patch)
     (1, 32, 31, 39, 64, 3, 2),       # stride 2 from odd input sizes -> 16 x 20: the patch runs past the right / bottom border
     (3, 128, 20, 20, 128, 3, 1),     # 6 x 20 tiles on the 20x20 maps of the model (partial last tile row)
+    (2, 256, 20, 20, 288, 1, 1),     # wide layers (N, C >= 256): 256 x 128 tiles forward AND input gradient, partial tiles in both directions
+    (1, 256, 26, 22, 256, 3, 2),     # the same through 9 taps at stride 2 (the input gradient's parity launches have K = 256 .. 1024)
 ]
 
 
