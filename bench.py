@@ -47,7 +47,7 @@ FAMILIES = {
     "depthwise conv": {"calls": (), "symbols": ("dw3x3_kernel", "dwconv_")},
     "batchnorm": {"calls": ("sy11_bn_act_fwd", "sy11_bn_act_bwd_reduce", "sy11_bn_act_bwd_apply", "sy11_bn_finalize"),
                   "symbols": ("bn_act_fwd_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "bn_finalize_kernel")},
-    "stem": {"calls": ("sy11_stem_conv_fwd", "sy11_stem_conv_wgrad"), "symbols": ("stem_fwd_mma", "stem_wgrad_mma")},
+    "stem": {"calls": ("sy11_stem_conv_fwd", "sy11_stem_conv_wgrad"), "symbols": ("stem_fwd_tile", "stem_wgrad_tile", "stem_fwd_mma", "stem_wgrad_mma")},
 }
 
 
