@@ -384,6 +384,160 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ 3x3 stride-1: patch kernel (r03)
+// The GEMM kernels above fetch an input pixel once per TAP (the nine (tap, channel) column tiles are different workgroups or
+// different stages): 32-64 FLOP per byte through the CU's 64 B/clk address path, which is what bounds them.  Here a workgroup
+// owns a 64-channel x 64-filter block of dW for ALL nine taps: a stage is 80 output pixels (one row of an 80-wide map, two rows
+// of a 40-wide, four of a 20-wide one) and its (rows + 2) x (width + 2) input patch, staged ONCE as [patch pixel][channel] in LDS;
+// the nine taps are nine row offsets into that patch for the transposing fragment read.  142 FLOP per staged byte.
+// Waves 2 x 2 over (filter block, channel block) of 32 x 32, nine accumulator tiles each (144 registers).
+// One tap ROW (ty) per workgroup: the patch is the stage's own rows shifted by ty - 1, two columns wider.  (All nine taps per
+// workgroup — 142 FLOP per staged byte — was measured first and lost: 147 KB of f32 atomics per workgroup, 38 MB per layer at one
+// workgroup per CU; a tap row has a third of that per workgroup and three times the workgroups.)  SP = pixels per stage.
+template <typename T, int WS, int SP>
+__global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const WgradArgs a) {
+  constexpr int NTY = 1, RS = SP / WS, PW = WS + 2, PHT = RS + NTY - 1, NPX = PHT * PW, NT = 3 * NTY;
+  constexpr int ROWB = 64 * 2 + 64;                 // LDS row: 64 values + 64 bytes (4 consecutive rows on 4 disjoint bank ranges)
+  constexpr int XB = NPX * ROWB, DB = SP * ROWB;
+  constexpr int XCH = (NPX * 8 + 255) / 256, DCH = (SP * 8 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[XB + DB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_xcd = gridDim.x >> 3;
+  const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (vid >= a.total) return;
+  const int split = vid / a.tiles, tile = vid - split * a.tiles;
+  // tile = ((tn * tiles_k) + tc) * (3 / NTY) + ty0: the tap rows of one block are neighbours (they read the same dy rows)
+  constexpr int TYT = 3 / NTY;
+  const int ty0 = tile % TYT, tcn = tile / TYT;
+  const int tc = tcn % a.tiles_k, tn = tcn / a.tiles_k;
+  const int c0 = tc * 64, n0 = tn * 64;
+  const int sps = a.pix_per_split / SP, stages = a.M / SP;
+  const int s_begin = split * sps, s_end = min(stages, s_begin + sps);
+  float* const dwp = a.dw + (long)split * a.dw_split_stride;
+  if (s_begin >= s_end) return;
+  const int SX = a.OW / WS, spi = (a.OH / RS) * SX;            // stages per row band, per image
+  const int row0 = NTY == 3 ? -1 : ty0 - 1;                    // first patch row relative to the stage's first output row
+
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const int x_pixb = a.x_ld * 2, dy_rowb = a.dy_ld * 2;
+  // this thread's 16-byte chunks of a stage: fixed patch position / stage pixel, only the stage origin moves
+  int xconst[XCH], xrc[XCH], dconst[DCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    const int cidx = tid + 256 * i, px = cidx >> 3, ch = cidx & 7;
+    const int pr = px / PW, pc = px - pr * PW;
+    xconst[i] = ((pr + row0) * a.IW + (pc - 1)) * x_pixb + (c0 + ch * 8) * 2;
+    xrc[i] = px < NPX ? (pr | (pc << 8)) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < DCH; ++i) {
+    const int cidx = tid + 256 * i, p = cidx >> 3, ch = cidx & 7;
+    const int oyl = p / WS, oxl = p - oyl * WS;
+    dconst[i] = p < SP ? (oyl * a.OW + oxl) * dy_rowb + (n0 + ch * 8) * 2 : -1;
+  }
+  uint4 rx[XCH], rd[DCH];
+  auto load_stage = [&](int g) {
+    const int b = g / spi, j = g - b * spi, jy = j / SX;
+    const int oy0 = jy * RS, ox0 = (j - jy * SX) * WS;
+    const int xbase = ((b * a.IH + oy0) * a.IW + ox0) * x_pixb;                  // host: the x / dy views are < 2^31 bytes
+    const int dbase = ((b * a.OH + oy0) * a.OW + ox0) * dy_rowb;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int iy = oy0 + row0 + (xrc[i] & 255), ix = ox0 - 1 + (xrc[i] >> 8);
+      const bool in = xrc[i] >= 0 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, in ? (unsigned)(xbase + xconst[i]) : OOB, 0, 0);
+      rx[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) {
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(dr, dconst[i] >= 0 ? (unsigned)(dbase + dconst[i]) : OOB, 0, 0);
+      rd[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int cidx = tid + 256 * i;
+      if (cidx < NPX * 8) *(uint4*)(smem + (cidx >> 3) * ROWB + (cidx & 7) * 16) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) {
+      const int cidx = tid + 256 * i;
+      if (cidx < SP * 8) *(uint4*)(smem + XB + (cidx >> 3) * ROWB + (cidx & 7) * 16) = rd[i];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  const int wr = wave >> 1, wc = wave & 1;                      // filter block (rows of dW), channel block
+  const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+  const int colb = ((grp & 1) * 16 + p4 * 4) * 2;
+  const int dlane = XB + ((grp >> 1) * 8 + q) * ROWB + colb + wr * 64;
+  // patch row of this lane's pixels at the workgroup's first tap: k-step ks, pixels ks*16 + 8*(grp>>1) + q (+4)
+  int xoff[SP / 16][2];
+#pragma unroll
+  for (int ks = 0; ks < SP / 16; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = ks * 16 + (grp >> 1) * 8 + q + 4 * h;
+      const int oyl = p / WS, oxl = p - oyl * WS;
+      xoff[ks][h] = (oyl * PW + oxl) * ROWB + colb + wc * 64;
+    }
+
+  load_stage(s_begin);
+  for (int s = s_begin; s < s_end; ++s) {
+    if (s > s_begin) __syncthreads();                 // every wave is done reading the previous stage
+    store_stage();
+    __syncthreads();
+    if (s + 1 < s_end) load_stage(s + 1);             // in flight while this stage is multiplied
+#pragma unroll
+    for (int ks = 0; ks < SP / 16; ++ks) {
+      s16x8 fa;
+      {
+        const unsigned char* pa = smem + dlane + ks * 16 * ROWB;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWB));
+        fa = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int tapc = ((t / 3) * PW + (t % 3)) * ROWB;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + xoff[ks][0] + tapc));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + xoff[ks][1] + tapc));
+        const s16x8 fb = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[t] = Mma16<T>::run(fa, fb, acc[t]);
+      }
+    }
+  }
+  // dW[n][t][c]: D rows = filters (dy), columns = channels (x)
+  const int fcol = lane & 31, fh = lane >> 5;
+  float* base = dwp + (long)(n0 + wr * 32 + 4 * fh) * a.K + (NTY == 3 ? 0 : ty0 * 3) * a.C + c0 + wc * 32 + fcol;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) atomicAdd(base + (long)((e & 3) + 8 * (e >> 2)) * a.K + t * a.C, acc[t][e]);
+}
+
+// shapes the patch kernel takes: 3x3, stride 1, padding 1, dilation 1 (taps in row-major order), 64-channel / 64-filter blocks,
+// output width 20, 40 or a multiple of 80, whole stages per image
+static int wgrad3x3p_ws(const WgradArgs& a) {
+  if (a.T != 9 || a.sy != 1 || a.sx != 1 || a.C % 64 || a.N % 64 || a.IH != a.OH || a.IW != a.OW) return 0;
+  for (int t = 0; t < 9; ++t)
+    if (a.tap_dy[t] != t / 3 - 1 || a.tap_dx[t] != t % 3 - 1) return 0;
+  const int ws = a.OW % 80 == 0 ? 80 : (a.OW == 40 ? 40 : (a.OW == 20 ? 20 : 0));
+  if (!ws || a.OH % (80 / ws)) return 0;
+  return ws;
+}
+// pixels per stage: 160 where the map has whole 160-pixel stages (two barriers per 30 MFMAs instead of per 15), else 80
+static int wgrad3x3p_sp(const WgradArgs& a, int ws) { return (ws >= 40 && a.OH % (160 / ws) == 0) ? 160 : 80; }
+
 static int cu_count() {
   static int n = 0;
   if (!n) {
@@ -399,20 +553,26 @@ static int cu_count() {
 // adds only ~1.3 TB/s of them: one round of 128-wide tiles is 33.5 MB = 26 us, so small layers want FEWER workgroups).  A "round" = CUs x workgroups that fit one CU (LDS: 2 for
 // the 128-wide tile, 3 for the 64-wide); the pixel-split count is rounded DOWN so the grid never spills a nearly empty
 // extra round (1048 workgroups on 512 slots ran three rounds for two rounds of work).
-constexpr int WGRAD_NCFG = 12;
+// kind 3 (16-bit, 3x3 stride 1 shapes of wgrad3x3p_ws): the patch kernel, one tap row per workgroup, r rounds of resident workgroups
+constexpr int WGRAD_NCFG = 16;
 static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   const int kind = cfg >> 2;
   const bool psplit = kind == 2;
+  const bool patch = kind == 3;
+  const int patch_ws = patch ? wgrad3x3p_ws(a) : 0;
+  if (patch && (!patch_ws || dtype == SY11_F32)) SY11_FAIL(SY11_EUNSUPPORTED, "conv2d_wgrad: configuration %d does not take this shape", cfg);
+  const int patch_sp = patch ? wgrad3x3p_sp(a, patch_ws) : 0;
   const int tile = kind == 1 ? 128 : 64;
-  const int slots = cu_count() * (tile == 128 ? 2 : 3);
+  const int slots = cu_count() * (patch ? (patch_sp == 80 ? 4 : 2) : (tile == 128 ? 2 : 3));
   const int target_wg = (slots << (cfg & 3)) >> 2;
-  a.tiles_k = cdiv(a.K, tile);
-  const int tiles = a.tiles_k * cdiv(a.N, tile);
+  a.tiles_k = patch ? a.C / 64 : cdiv(a.K, tile);
+  const int tiles = a.tiles_k * cdiv(a.N, tile) * (patch ? 3 : 1);
   int splits = target_wg / tiles;
-  const int max_splits = cdiv(a.M, 512);               // >= 8 stages of 64 pixels per split
+  const int stage_px = patch ? patch_sp : 64;
+  const int max_splits = cdiv(a.M, 8 * stage_px);      // >= 8 stages per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  a.pix_per_split = cdiv(cdiv(a.M, splits), 64) * 64;
+  a.pix_per_split = cdiv(cdiv(a.M, splits), stage_px) * stage_px;
   splits = cdiv(a.M, a.pix_per_split);
   a.tiles = tiles; a.total = tiles * splits;
   // ordered mode: one partial dW per pixel split, folded in split order afterwards (a single split adds straight into dW: one
@@ -431,6 +591,17 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   if (dtype == SY11_F32) {
     if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<float, 64>), grid, block, 0, st, a);
+  } else if (patch) {
+#define SY11_WG3(TT)                                                                                       \
+    do {                                                                                                   \
+      if (patch_ws == 80 && patch_sp == 160) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 80, 160>), grid, block, 0, st, a); \
+      else if (patch_ws == 80) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 80, 80>), grid, block, 0, st, a);   \
+      else if (patch_ws == 40 && patch_sp == 160) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 40, 160>), grid, block, 0, st, a); \
+      else if (patch_ws == 40) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 40, 80>), grid, block, 0, st, a);   \
+      else hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 20, 80>), grid, block, 0, st, a);                       \
+    } while (0)
+    if (dtype == SY11_F16) SY11_WG3(_Float16); else SY11_WG3(__bf16);
+#undef SY11_WG3
   } else if (dtype == SY11_F16) {
     if (psplit) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 64, true>), grid, block, 0, st, a);
     else if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 128>), grid, block, 0, st, a);
@@ -492,7 +663,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
   int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 4 : 0) + 2;
   const int forced = sy11_opt(OPT_WGRAD_CFG);
   const int ncfg = d->dtype == SY11_F32 ? 8 : WGRAD_NCFG;
-  if (forced >= 0 && forced < ncfg) return wgrad_launch_cfg(a, d->dtype, st, forced);
+  if (forced >= 0 && forced < ncfg && (forced < 12 || wgrad3x3p_ws(a))) return wgrad_launch_cfg(a, d->dtype, st, forced);
   {                                  // a recorded / imported pick is honoured even with measuring off
     sy11tune::Cache& cache = sy11tune::cache(1);
     static float* scratch = nullptr;
@@ -501,7 +672,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
     const uint64_t h = sy11tune::hash(key, (int)(sizeof(key) / sizeof(int)));
     int hit;
     if (cache.get(h, &hit)) {
-      if (hit >= 0 && hit < ncfg) cfg = hit;          // an imported record from another build / a corrupt file: keep the heuristic
+      if (hit >= 0 && hit < ncfg && (hit < 12 || wgrad3x3p_ws(a))) cfg = hit;      // an imported record from another build / a corrupt file: keep the heuristic
     } else if (sy11tune::enabled() && !sy11tune::capturing(st)) {
       const size_t need = (size_t)a.N * a.K;
       if (need > scratch_elems) {                       // candidates accumulate with atomics: measure into a scratch dW
@@ -512,8 +683,10 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
       if (scratch) {
         WgradArgs t = a;
         t.dw = scratch;
-        const int cands[WGRAD_NCFG] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-        const int best = sy11tune::pick(cands, ncfg, [&](int c) { return wgrad_launch_cfg(t, d->dtype, st, c); }, st, "wgrad", key,
+        int cands[WGRAD_NCFG], nc = 0;
+        for (int c = 0; c < ncfg; ++c)
+          if (c < 12 || wgrad3x3p_ws(a)) cands[nc++] = c;
+        const int best = sy11tune::pick(cands, nc, [&](int c) { return wgrad_launch_cfg(t, d->dtype, st, c); }, st, "wgrad", key,
                                         (int)(sizeof(key) / sizeof(int)));
         if (best >= 0) { cache.put(h, best); cfg = best; }
       }

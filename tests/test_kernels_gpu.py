@@ -127,6 +127,11 @@ CFG_CASES = [
     (1, 64, 80, 80, 40, 3, 2),       # stride 2 -> 40x40 (3 x 40 tiles over an 81-column patch)
     (1, 32, 31, 39, 64, 3, 2),       # stride 2 from odd input sizes -> 16 x 20: the patch runs past the right / bottom border
     (3, 128, 20, 20, 128, 3, 1),     # 6 x 20 tiles on the 20x20 maps of the model (partial last tile row)
+    # shapes the patch filter-gradient kernel (wgrad cfg 12-15) takes: 3x3 stride 1, 64-blocks, 80 pixels per stage
+    (2, 64, 40, 40, 64, 3, 1),       # two rows of a 40-wide map per stage
+    (1, 128, 6, 80, 64, 3, 1),       # two rows of an 80-wide map per stage (160 pixels), two channel blocks
+    (1, 64, 5, 80, 64, 3, 1),        # an odd row count: one row (80 pixels) per stage
+    (1, 64, 4, 160, 128, 3, 1),      # half a row of a 160-wide map per stage, two filter blocks
     (2, 256, 20, 20, 288, 1, 1),     # wide layers (N, C >= 256): 256 x 128 tiles forward AND input gradient, partial tiles in both directions
     (1, 256, 26, 22, 256, 3, 2),     # the same through 9 taps at stride 2 (the input gradient's parity launches have K = 256 .. 1024)
 ]
@@ -168,7 +173,7 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
             o.conv2d_dgrad(dyv, wt, dx, (B, OH, OW, N), k, s, p, accumulate=True)
             close(to_nchw(dx), 2 * ref_dx, dtype, f"dgrad accumulate cfg {cfg}", mult=2)
         _lib.set_option("igemm_cfg", -1)
-        for cfg in range(12):
+        for cfg in range(16):
             _lib.set_option("wgrad_cfg", cfg)
             dw = torch.zeros(N, k, k, Cn, dtype=torch.float32, device=DEV)
             o.conv2d_wgrad(xv, dyv, dw, k, s, p)
