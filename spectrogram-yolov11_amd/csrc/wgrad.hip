@@ -393,13 +393,19 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
 // Waves 2 x 2 over (filter block, channel block) of 32 x 32, nine accumulator tiles each (144 registers).
 // One tap ROW (ty) per workgroup: the patch is the stage's own rows shifted by ty - 1, two columns wider.  (All nine taps per
 // workgroup — 142 FLOP per staged byte — was measured first and lost: 147 KB of f32 atomics per workgroup, 38 MB per layer at one
-// workgroup per CU; a tap row has a third of that per workgroup and three times the workgroups.)  SP = pixels per stage.
-template <typename T, int WS, int SP>
+// workgroup per CU; a tap row has a third of that per workgroup and three times the workgroups.)  SP = pixels per stage;
+// CB x NB = channels x filters per workgroup (32 or 64 each; partial blocks are zero-filled on the way in and masked on the way
+// out).  The (NB/32) x (CB/32) blocks of 32 x 32 go to the four waves; with fewer than four blocks the waves of a block share its
+// k-steps (pixels) and each adds its partial sums.
+// (Nine taps per workgroup was also tried again for the <= 32-channel layers, whose dW is only 18-74 KB: 99-115 us against 68.)
+template <typename T, int WS, int SP, int CB, int NB>
 __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const WgradArgs a) {
-  constexpr int NTY = 1, RS = SP / WS, PW = WS + 2, PHT = RS + NTY - 1, NPX = PHT * PW, NT = 3 * NTY;
-  constexpr int ROWB = 64 * 2 + 64;                 // LDS row: 64 values + 64 bytes (4 consecutive rows on 4 disjoint bank ranges)
-  constexpr int XB = NPX * ROWB, DB = SP * ROWB;
-  constexpr int XCH = (NPX * 8 + 255) / 256, DCH = (SP * 8 + 255) / 256;
+  constexpr int NTY = 1, RS = SP / WS, PW = WS + 2, NPX = (RS + NTY - 1) * PW, NT = 3 * NTY;
+  constexpr int ROWX = CB * 2 + (CB == 64 ? 64 : 0), ROWD = NB * 2 + (NB == 64 ? 64 : 0);    // row strides = 64 mod 256 bytes
+  constexpr int XB = NPX * ROWX, DB = SP * ROWD;
+  constexpr int CCH = CB / 8, NCH = NB / 8;                        // 16-byte chunks per pixel
+  constexpr int XCH = (NPX * CCH + 255) / 256, DCH = (SP * NCH + 255) / 256;
+  constexpr int NBLK = (CB / 32) * (NB / 32), KH = 4 / NBLK, KS = SP / 16, KPW = (KS + KH - 1) / KH;
   __shared__ __attribute__((aligned(16))) unsigned char smem[XB + DB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -407,17 +413,17 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
   const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (vid >= a.total) return;
   const int split = vid / a.tiles, tile = vid - split * a.tiles;
-  // tile = ((tn * tiles_k) + tc) * (3 / NTY) + ty0: the tap rows of one block are neighbours (they read the same dy rows)
+  // tile = ((tn * tiles_k) + tc) * 3 + ty: the tap rows of one block are neighbours (they read the same dy rows)
   constexpr int TYT = 3 / NTY;
-  const int ty0 = tile % TYT, tcn = tile / TYT;
+  const int ty = tile % TYT, tcn = tile / TYT;
   const int tc = tcn % a.tiles_k, tn = tcn / a.tiles_k;
-  const int c0 = tc * 64, n0 = tn * 64;
+  const int c0 = tc * CB, n0 = tn * NB;
   const int sps = a.pix_per_split / SP, stages = a.M / SP;
   const int s_begin = split * sps, s_end = min(stages, s_begin + sps);
   float* const dwp = a.dw + (long)split * a.dw_split_stride;
   if (s_begin >= s_end) return;
   const int SX = a.OW / WS, spi = (a.OH / RS) * SX;            // stages per row band, per image
-  const int row0 = NTY == 3 ? -1 : ty0 - 1;                    // first patch row relative to the stage's first output row
+  const int row0 = NTY == 3 ? -1 : ty - 1;                     // first patch row relative to the stage's first output row
 
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
@@ -428,16 +434,16 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
   int xconst[XCH], xrc[XCH], dconst[DCH];
 #pragma unroll
   for (int i = 0; i < XCH; ++i) {
-    const int cidx = tid + 256 * i, px = cidx >> 3, ch = cidx & 7;
+    const int cidx = tid + 256 * i, px = cidx / CCH, ch = cidx - px * CCH;
     const int pr = px / PW, pc = px - pr * PW;
     xconst[i] = ((pr + row0) * a.IW + (pc - 1)) * x_pixb + (c0 + ch * 8) * 2;
-    xrc[i] = px < NPX ? (pr | (pc << 8)) : -1;
+    xrc[i] = (px < NPX && c0 + ch * 8 < a.C) ? (pr | (pc << 8)) : -1;
   }
 #pragma unroll
   for (int i = 0; i < DCH; ++i) {
-    const int cidx = tid + 256 * i, p = cidx >> 3, ch = cidx & 7;
+    const int cidx = tid + 256 * i, p = cidx / NCH, ch = cidx - p * NCH;
     const int oyl = p / WS, oxl = p - oyl * WS;
-    dconst[i] = p < SP ? (oyl * a.OW + oxl) * dy_rowb + (n0 + ch * 8) * 2 : -1;
+    dconst[i] = (p < SP && n0 + ch * 8 < a.N) ? (oyl * a.OW + oxl) * dy_rowb + (n0 + ch * 8) * 2 : -1;
   }
   uint4 rx[XCH], rd[DCH];
   auto load_stage = [&](int g) {
@@ -461,13 +467,13 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
   auto store_stage = [&]() {
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-      const int cidx = tid + 256 * i;
-      if (cidx < NPX * 8) *(uint4*)(smem + (cidx >> 3) * ROWB + (cidx & 7) * 16) = rx[i];
+      const int cidx = tid + 256 * i, px = cidx / CCH, ch = cidx - px * CCH;
+      if (cidx < NPX * CCH) *(uint4*)(smem + px * ROWX + ch * 16) = rx[i];
     }
 #pragma unroll
     for (int i = 0; i < DCH; ++i) {
-      const int cidx = tid + 256 * i;
-      if (cidx < SP * 8) *(uint4*)(smem + XB + (cidx >> 3) * ROWB + (cidx & 7) * 16) = rd[i];
+      const int cidx = tid + 256 * i, p = cidx / NCH, ch = cidx - p * NCH;
+      if (cidx < SP * NCH) *(uint4*)(smem + XB + p * ROWD + ch * 16) = rd[i];
     }
   };
 
@@ -476,20 +482,21 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  const int wr = wave >> 1, wc = wave & 1;                      // filter block (rows of dW), channel block
+  const int blk = wave % NBLK, kh = wave / NBLK;                // this wave's 32 x 32 block and its share of the k-steps
+  const int wr = blk % (NB / 32), wc = blk / (NB / 32);         // filter block (rows of dW), channel block
   const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
   const int colb = ((grp & 1) * 16 + p4 * 4) * 2;
-  const int dlane = XB + ((grp >> 1) * 8 + q) * ROWB + colb + wr * 64;
-  // patch row of this lane's pixels at the workgroup's first tap: k-step ks, pixels ks*16 + 8*(grp>>1) + q (+4)
-  int xoff[SP / 16][2];
+  // fragment rows of this lane, per k-step of this wave: dy pixel row / patch row at tx = 0, pixels ks*16 + 8*(grp>>1) + q (+4)
+  int xoff[KPW][2];
 #pragma unroll
-  for (int ks = 0; ks < SP / 16; ++ks)
+  for (int k = 0; k < KPW; ++k)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int p = ks * 16 + (grp >> 1) * 8 + q + 4 * h;
+      const int p = min((k * KH + kh) * 16, SP - 16) + (grp >> 1) * 8 + q + 4 * h;
       const int oyl = p / WS, oxl = p - oyl * WS;
-      xoff[ks][h] = (oyl * PW + oxl) * ROWB + colb + wc * 64;
+      xoff[k][h] = (oyl * PW + oxl) * ROWX + colb + wc * 64;
     }
+  const int dlane = XB + ((grp >> 1) * 8 + q) * ROWD + colb + wr * 64;
 
   load_stage(s_begin);
   for (int s = s_begin; s < s_end; ++s) {
@@ -498,19 +505,21 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
     __syncthreads();
     if (s + 1 < s_end) load_stage(s + 1);             // in flight while this stage is multiplied
 #pragma unroll
-    for (int ks = 0; ks < SP / 16; ++ks) {
+    for (int k = 0; k < KPW; ++k) {
+      const int ks = k * KH + kh;
+      if (KS % KH != 0 && ks >= KS) break;            // (wave-uniform) the last round of k-steps is not full
       s16x8 fa;
       {
-        const unsigned char* pa = smem + dlane + ks * 16 * ROWB;
+        const unsigned char* pa = smem + dlane + ks * 16 * ROWD;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWD));
         fa = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int tapc = ((t / 3) * PW + (t % 3)) * ROWB;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + xoff[ks][0] + tapc));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + xoff[ks][1] + tapc));
+        const int tapc = ((t / 3) * PW + (t % 3)) * ROWX;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + xoff[k][0] + tapc));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + xoff[k][1] + tapc));
         const s16x8 fb = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         acc[t] = Mma16<T>::run(fa, fb, acc[t]);
       }
@@ -518,17 +527,23 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
   }
   // dW[n][t][c]: D rows = filters (dy), columns = channels (x)
   const int fcol = lane & 31, fh = lane >> 5;
-  float* base = dwp + (long)(n0 + wr * 32 + 4 * fh) * a.K + (NTY == 3 ? 0 : ty0 * 3) * a.C + c0 + wc * 32 + fcol;
+  const int cc = c0 + wc * 32 + fcol, nr = n0 + wr * 32 + 4 * fh;
+  float* base = dwp + (long)nr * a.K + (NTY == 3 ? 0 : ty * 3) * a.C + cc;
+  if (cc < a.C) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) atomicAdd(base + (long)((e & 3) + 8 * (e >> 2)) * a.K + t * a.C, acc[t][e]);
+      for (int e = 0; e < 16; ++e) {
+        const int dn = (e & 3) + 8 * (e >> 2);
+        if (nr + dn < a.N) atomicAdd(base + (long)dn * a.K + t * a.C, acc[t][e]);
+      }
+  }
 }
 
 // shapes the patch kernel takes: 3x3, stride 1, padding 1, dilation 1 (taps in row-major order), 64-channel / 64-filter blocks,
 // output width 20, 40 or a multiple of 80, whole stages per image
 static int wgrad3x3p_ws(const WgradArgs& a) {
-  if (a.T != 9 || a.sy != 1 || a.sx != 1 || a.C % 64 || a.N % 64 || a.IH != a.OH || a.IW != a.OW) return 0;
+  if (a.T != 9 || a.sy != 1 || a.sx != 1 || a.C % 8 || a.N % 8 || a.IH != a.OH || a.IW != a.OW) return 0;
   for (int t = 0; t < 9; ++t)
     if (a.tap_dy[t] != t / 3 - 1 || a.tap_dx[t] != t % 3 - 1) return 0;
   const int ws = a.OW % 80 == 0 ? 80 : (a.OW == 40 ? 40 : (a.OW == 20 ? 20 : 0));
@@ -565,8 +580,9 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   const int tile = kind == 1 ? 128 : 64;
   const int slots = cu_count() * (patch ? (patch_sp == 80 ? 4 : 2) : (tile == 128 ? 2 : 3));
   const int target_wg = (slots << (cfg & 3)) >> 2;
-  a.tiles_k = patch ? a.C / 64 : cdiv(a.K, tile);
-  const int tiles = a.tiles_k * cdiv(a.N, tile) * (patch ? 3 : 1);
+  const int pcb = a.C > 32 ? 64 : 32, pnb = a.N > 32 ? 64 : 32;          // patch kernel: channels x filters per workgroup
+  a.tiles_k = patch ? cdiv(a.C, pcb) : cdiv(a.K, tile);
+  const int tiles = patch ? a.tiles_k * cdiv(a.N, pnb) * 3 : a.tiles_k * cdiv(a.N, tile);
   int splits = target_wg / tiles;
   const int stage_px = patch ? patch_sp : 64;
   const int max_splits = cdiv(a.M, 8 * stage_px);      // >= 8 stages per split
@@ -592,16 +608,24 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
     if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<float, 64>), grid, block, 0, st, a);
   } else if (patch) {
-#define SY11_WG3(TT)                                                                                       \
-    do {                                                                                                   \
-      if (patch_ws == 80 && patch_sp == 160) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 80, 160>), grid, block, 0, st, a); \
-      else if (patch_ws == 80) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 80, 80>), grid, block, 0, st, a);   \
-      else if (patch_ws == 40 && patch_sp == 160) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 40, 160>), grid, block, 0, st, a); \
-      else if (patch_ws == 40) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 40, 80>), grid, block, 0, st, a);   \
-      else hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 20, 80>), grid, block, 0, st, a);                       \
+#define SY11_WG3B(TT, CBB, NBB)                                                                                       \
+    do {                                                                                                              \
+      if (patch_ws == 80 && patch_sp == 160) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 80, 160, CBB, NBB>), grid, block, 0, st, a); \
+      else if (patch_ws == 80) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 80, 80, CBB, NBB>), grid, block, 0, st, a);   \
+      else if (patch_ws == 40 && patch_sp == 160) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 40, 160, CBB, NBB>), grid, block, 0, st, a); \
+      else if (patch_ws == 40) hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 40, 80, CBB, NBB>), grid, block, 0, st, a);   \
+      else hipLaunchKernelGGL((wgrad3x3p_kernel<TT, 20, 80, CBB, NBB>), grid, block, 0, st, a);                       \
+    } while (0)
+#define SY11_WG3(TT)                                                   \
+    do {                                                               \
+      if (pcb == 64 && pnb == 64) SY11_WG3B(TT, 64, 64);               \
+      else if (pcb == 64) SY11_WG3B(TT, 64, 32);                       \
+      else if (pnb == 64) SY11_WG3B(TT, 32, 64);                       \
+      else SY11_WG3B(TT, 32, 32);                                      \
     } while (0)
     if (dtype == SY11_F16) SY11_WG3(_Float16); else SY11_WG3(__bf16);
 #undef SY11_WG3
+#undef SY11_WG3B
   } else if (dtype == SY11_F16) {
     if (psplit) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 64, true>), grid, block, 0, st, a);
     else if (tile == 128) hipLaunchKernelGGL((wgrad16_kernel<_Float16, 128>), grid, block, 0, st, a);
@@ -663,7 +687,8 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
   int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 4 : 0) + 2;
   const int forced = sy11_opt(OPT_WGRAD_CFG);
   const int ncfg = d->dtype == SY11_F32 ? 8 : WGRAD_NCFG;
-  if (forced >= 0 && forced < ncfg && (forced < 12 || wgrad3x3p_ws(a))) return wgrad_launch_cfg(a, d->dtype, st, forced);
+  auto patch_ok = [&](int c) { return c < 12 || wgrad3x3p_ws(a) != 0; };
+  if (forced >= 0 && forced < ncfg && patch_ok(forced)) return wgrad_launch_cfg(a, d->dtype, st, forced);
   {                                  // a recorded / imported pick is honoured even with measuring off
     sy11tune::Cache& cache = sy11tune::cache(1);
     static float* scratch = nullptr;
@@ -672,7 +697,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
     const uint64_t h = sy11tune::hash(key, (int)(sizeof(key) / sizeof(int)));
     int hit;
     if (cache.get(h, &hit)) {
-      if (hit >= 0 && hit < ncfg && (hit < 12 || wgrad3x3p_ws(a))) cfg = hit;      // an imported record from another build / a corrupt file: keep the heuristic
+      if (hit >= 0 && hit < ncfg && patch_ok(hit)) cfg = hit;      // an imported record from another build / a corrupt file: keep the heuristic
     } else if (sy11tune::enabled() && !sy11tune::capturing(st)) {
       const size_t need = (size_t)a.N * a.K;
       if (need > scratch_elems) {                       // candidates accumulate with atomics: measure into a scratch dW
@@ -685,7 +710,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
         t.dw = scratch;
         int cands[WGRAD_NCFG], nc = 0;
         for (int c = 0; c < ncfg; ++c)
-          if (c < 12 || wgrad3x3p_ws(a)) cands[nc++] = c;
+          if (patch_ok(c)) cands[nc++] = c;
         const int best = sy11tune::pick(cands, nc, [&](int c) { return wgrad_launch_cfg(t, d->dtype, st, c); }, st, "wgrad", key,
                                         (int)(sizeof(key) / sizeof(int)));
         if (best >= 0) { cache.put(h, best); cfg = best; }

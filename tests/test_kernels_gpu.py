@@ -131,6 +131,10 @@ CFG_CASES = [
     (2, 64, 40, 40, 64, 3, 1),       # two rows of a 40-wide map per stage
     (1, 128, 6, 80, 64, 3, 1),       # two rows of an 80-wide map per stage (160 pixels), two channel blocks
     (1, 64, 5, 80, 64, 3, 1),        # an odd row count: one row (80 pixels) per stage
+    (1, 32, 4, 80, 64, 3, 1),        # 32-channel block: two waves share the k-steps of a 32 x 32 block
+    (1, 64, 3, 80, 32, 3, 1),        # 32-filter block, 80-pixel stages
+    (1, 16, 2, 160, 32, 3, 1),       # 16 of 32 channels real, one block: four waves share its k-steps
+    (1, 32, 2, 160, 16, 3, 1),       # 16 of 32 filters real
     (1, 64, 4, 160, 128, 3, 1),      # half a row of a 160-wide map per stage, two filter blocks
     (2, 256, 20, 20, 288, 1, 1),     # wide layers (N, C >= 256): 256 x 128 tiles forward AND input gradient, partial tiles in both directions
     (1, 256, 26, 22, 256, 3, 2),     # the same through 9 taps at stride 2 (the input gradient's parity launches have K = 256 .. 1024)

@@ -9,7 +9,7 @@ from sy11 import ops, _lib
 from bn_sweep import timed
 
 B, dt = 64, torch.float16
-SHAPES = [(80, 80, 64, 64, 1), (80, 80, 128, 64, 1), (40, 40, 64, 64, 5), (40, 40, 64, 128, 2), (40, 40, 128, 64, 2), (40, 40, 256, 64, 1),
+SHAPES = [(160, 160, 16, 32, 1), (160, 160, 32, 16, 1), (80, 80, 32, 64, 2), (80, 80, 64, 32, 2), (80, 80, 64, 64, 1), (80, 80, 128, 64, 1), (40, 40, 64, 64, 5), (40, 40, 64, 128, 2), (40, 40, 128, 64, 2), (40, 40, 256, 64, 1),
           (20, 20, 64, 64, 1), (20, 20, 128, 128, 8), (20, 20, 512, 64, 1)]
 
 
