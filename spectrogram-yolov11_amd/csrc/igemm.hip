@@ -504,7 +504,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // 9..11 = the first three with a 4-deep ring of 64-byte stages (3 stages in flight); 12..14 = 128-byte stages, 3-deep ring
 // 15, 16 = halo-tiled 3x3 kernel (conv3x3.hip) with the widest / the next narrower channel tile
 // 17, 18 = the same with 256-pixel tiles (stride 1): half the filter bytes per FLOP
-constexpr int IGEMM_NCFG = 19;
+// 19 = few-channel 3x3 stride-1 kernel (conv3x3s.hip): C = 16 / 32, N <= 32, the filter resident in registers
+constexpr int IGEMM_NCFG = 20;
 static int halo_bn(const IgemmArgs& a, int cfg) {
   const int wide = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   const int bn = (cfg == 15 || cfg == 17) ? wide : (wide > 32 ? wide / 2 : 0);
@@ -524,6 +525,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
     const int bn = halo_bn(a, cfg);
     return std::is_same<T, _Float16>::value && bn > 0 && sy11_halo3x3_legal(a, bn);
   }
+  if (cfg == 19) return !std::is_same<T, float>::value && sy11_smallc3x3_legal(a);
   if (cfg == 7 || cfg == 8) {
     const int epi = epi_code(a), bn = cfg == 7 ? 128 : 64;
     if (std::is_same<T, float>::value || a.T != 1 || a.tap_dy[0] || a.tap_dx[0] || a.sy != 1 || a.sx != 1 || !a.dense_out || !a.vec_out) return false;
@@ -547,6 +549,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
 template <typename T>
 static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
   if (cfg >= 15 && cfg <= 18) return sy11_halo3x3_launch(a, halo_bn(a, cfg), st);
+  if (cfg == 19) return sy11_smallc3x3_launch(a, ElemTraits<T>::code, st);
   if (cfg == 7 || cfg == 8)
     return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
                                  a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st, a.bias);
@@ -634,6 +637,8 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
     const long wgs = (long)(a.M / (a.OH * a.OW)) * cdiv(a.OH, th) * cdiv(a.OW, tw) * cdiv(a.N, halo_bn(a, 15) % 1000);
     cfg = (wgs < 400 && cfg_legal<T>(a, 16)) ? 16 : 15;
   }
+  // few channels on both sides (160x160 16 <-> 32): the register-resident-filter kernel won every such layer (r03: 50-61 us against 88-97)
+  if (cfg_legal<T>(a, 19)) cfg = 19;
   if (forced >= 0 && cfg_legal<T>(a, forced)) return launch_cfg<T>(a, st, forced);
   if (dbg == 0) {                    // a recorded / imported pick is honoured even with measuring off ("tune" 0 only stops NEW measurements)
     sy11tune::Cache& cache = sy11tune::cache(0);

@@ -39,3 +39,6 @@ int sy11_halo3x3_launch(const IgemmArgs& a, int bn, hipStream_t st);
 // stride-2 3x3 input gradient, all four parity classes in one pass (conv3x3.hip); see the argument convention there
 bool sy11_halo_dgrad_s2_legal(const IgemmArgs& a);
 int sy11_halo_dgrad_s2_launch(const IgemmArgs& a, hipStream_t st);
+// few-channel 3x3 stride-1 kernel (conv3x3s.hip): C = 16 / 32, N <= 32, filters resident in registers; dtype = SY11_F16 / SY11_BF16
+bool sy11_smallc3x3_legal(const IgemmArgs& a);
+int sy11_smallc3x3_launch(const IgemmArgs& a, int dtype, hipStream_t st);

@@ -406,7 +406,8 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
   constexpr int CCH = CB / 8, NCH = NB / 8;                        // 16-byte chunks per pixel
   constexpr int XCH = (NPX * CCH + 255) / 256, DCH = (SP * NCH + 255) / 256;
   constexpr int NBLK = (CB / 32) * (NB / 32), KH = 4 / NBLK, KS = SP / 16, KPW = (KS + KH - 1) / KH;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[XB + DB];
+  constexpr int FOLD = KH > 1 ? NBLK * 3 * 16 * 64 * 4 : 0;        // epilogue: the partial tiles of the waves that share a block
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(XB + DB) > FOLD ? (XB + DB) : FOLD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per_xcd = gridDim.x >> 3;
@@ -524,6 +525,28 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
         acc[t] = Mma16<T>::run(fa, fb, acc[t]);
       }
     }
+  }
+  if constexpr (KH > 1) {
+    // the waves of one block fold their partial tiles in wave order through the (now idle) staging memory: one set of atomics per
+    // block instead of KH, and a fixed summation order inside the workgroup (the ordered mode relies on it)
+    float* fold = (float*)smem + blk * (3 * 16 * 64);
+    for (int r = 1; r < KH; ++r) {
+      __syncthreads();
+      if (kh == r) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) fold[(t * 16 + e) * 64 + lane] = acc[t][e];
+      }
+      __syncthreads();
+      if (kh == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[t][e] += fold[(t * 16 + e) * 64 + lane];
+      }
+    }
+    if (kh != 0) return;
   }
   // dW[n][t][c]: D rows = filters (dy), columns = channels (x)
   const int fcol = lane & 31, fh = lane >> 5;
@@ -685,6 +708,8 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
     }
   // static heuristic (r01 sweeps): 128-wide tiles unless the map is small, one round of workgroups, >= 512 pixels per split
   int cfg = ((a.N > 64 && a.K > 64 && a.M > 30000) ? 4 : 0) + 2;
+  // 3x3 stride 1 on the large maps: the patch kernel (r03 probe: it wins every such layer at >= 80x80 x 64 images, never at 20x20)
+  if (d->dtype != SY11_F32 && a.M >= 200000 && wgrad3x3p_ws(a)) cfg = 14;
   const int forced = sy11_opt(OPT_WGRAD_CFG);
   const int ncfg = d->dtype == SY11_F32 ? 8 : WGRAD_NCFG;
   auto patch_ok = [&](int c) { return c < 12 || wgrad3x3p_ws(a) != 0; };

@@ -127,6 +127,11 @@ CFG_CASES = [
     (1, 64, 80, 80, 40, 3, 2),       # stride 2 -> 40x40 (3 x 40 tiles over an 81-column patch)
     (1, 32, 31, 39, 64, 3, 2),       # stride 2 from odd input sizes -> 16 x 20: the patch runs past the right / bottom border
     (3, 128, 20, 20, 128, 3, 1),     # 6 x 20 tiles on the 20x20 maps of the model (partial last tile row)
+    # shapes the few-channel kernel (igemm cfg 19) takes, forward and input gradient: C, N in {16, 32}, ragged 4 x 64 / 8 x 32 tiles
+    (2, 16, 12, 70, 32, 3, 1),
+    (1, 32, 9, 130, 16, 3, 1),
+    (2, 32, 11, 96, 32, 3, 1),       # width a multiple of 32 but not of 64: 8 x 32 tiles
+    (1, 16, 20, 160, 16, 3, 1),
     # shapes the patch filter-gradient kernel (wgrad cfg 12-15) takes: 3x3 stride 1, 64-blocks, 80 pixels per stage
     (2, 64, 40, 40, 64, 3, 1),       # two rows of a 40-wide map per stage
     (1, 128, 6, 80, 64, 3, 1),       # two rows of an 80-wide map per stage (160 pixels), two channel blocks
@@ -164,7 +169,7 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
     tune0 = _lib.get_option("tune")
     try:
         _lib.set_option("tune", 0)
-        for cfg in range(19):
+        for cfg in range(20):
             _lib.set_option("igemm_cfg", cfg)
             y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
             ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
