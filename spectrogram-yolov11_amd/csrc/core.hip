@@ -136,7 +136,7 @@ extern "C" int sy11_tune_import(const void* buf, int64_t bytes) {
     uint64_t h; int32_t k, v;
     memcpy(&h, p, 8); memcpy(&k, p + 8, 4); memcpy(&v, p + 12, 4);
     SY11_REQUIRE(k == 0 || k == 1, "tune_import: record %ld has kind %d", (long)i, k);
-    SY11_REQUIRE(v >= 0 && v < (k == 0 ? 19 : 12), "tune_import: record %ld (kind %d) picks configuration %d, outside this build's table", (long)i, k, v);
+    SY11_REQUIRE(v >= 0 && v < (k == 0 ? SY11_IGEMM_NCFG : SY11_WGRAD_NCFG), "tune_import: record %ld (kind %d) picks configuration %d, outside this build's table", (long)i, k, v);
   }
   for (int64_t i = 0; i < bytes / 16; ++i) {           // all records valid: apply
     const unsigned char* p = (const unsigned char*)buf + i * 16;

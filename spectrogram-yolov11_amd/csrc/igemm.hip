@@ -505,7 +505,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // 15, 16 = halo-tiled 3x3 kernel (conv3x3.hip) with the widest / the next narrower channel tile
 // 17, 18 = the same with 256-pixel tiles (stride 1): half the filter bytes per FLOP
 // 19 = few-channel 3x3 stride-1 kernel (conv3x3s.hip): C = 16 / 32, N <= 32, the filter resident in registers
-constexpr int IGEMM_NCFG = 20;
+constexpr int IGEMM_NCFG = SY11_IGEMM_NCFG;
+static_assert(IGEMM_NCFG == 20, "configuration table and its size (tune.h) out of step");
 static int halo_bn(const IgemmArgs& a, int cfg) {
   const int wide = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   const int bn = (cfg == 15 || cfg == 17) ? wide : (wide > 32 ? wide / 2 : 0);

@@ -7,6 +7,11 @@
 // cached pick or fall back to the heuristic, so graph capture stays legal.  SY11_TUNE=0 disables measuring,
 // SY11_TUNE_LOG=1 prints every decision.
 #pragma once
+// sizes of the two tile-configuration tables (igemm.hip / wgrad.hip own the meaning of an index; core.hip validates imported picks
+// against these — ONE definition, so that adding a configuration cannot leave the importer behind)
+constexpr int SY11_IGEMM_NCFG = 20;
+constexpr int SY11_WGRAD_NCFG = 16;
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -592,7 +592,8 @@ static int cu_count() {
 // the 128-wide tile, 3 for the 64-wide); the pixel-split count is rounded DOWN so the grid never spills a nearly empty
 // extra round (1048 workgroups on 512 slots ran three rounds for two rounds of work).
 // kind 3 (16-bit, 3x3 stride 1 shapes of wgrad3x3p_ws): the patch kernel, one tap row per workgroup, r rounds of resident workgroups
-constexpr int WGRAD_NCFG = 16;
+constexpr int WGRAD_NCFG = SY11_WGRAD_NCFG;
+static_assert(WGRAD_NCFG == 16, "configuration table and its size (tune.h) out of step");
 static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   const int kind = cfg >> 2;
   const bool psplit = kind == 2;

@@ -95,3 +95,19 @@ def test_product_package_never_imports_the_oracle():
     for f in pkg.rglob("*.py"):
         t = f.read_text()
         assert "import oracle" not in t and "from oracle" not in t, f
+
+
+def test_tune_import_accepts_every_configuration_of_this_build_and_nothing_beyond():
+    """sy11_tune_import validates a pick against the SAME table sizes the kernels' files use (csrc/tune.h): the highest configuration
+    of each table imports, the next index is refused.  (r03: the few-channel conv and patch filter-gradient configurations were
+    added to the kernels while the importer still had the old sizes — rank 0's picks then failed to import on the other ranks.)"""
+    import struct
+    from sy11 import _lib
+    igemm_n, wgrad_n = 20, 16
+    _lib.tune_import(struct.pack("<Qii", 0xfeed0001, 0, igemm_n - 1) + struct.pack("<Qii", 0xfeed0002, 1, wgrad_n - 1))
+    blob = _lib.tune_export()
+    recs = {blob[i:i + 16] for i in range(0, len(blob), 16)}
+    assert struct.pack("<Qii", 0xfeed0001, 0, igemm_n - 1) in recs and struct.pack("<Qii", 0xfeed0002, 1, wgrad_n - 1) in recs
+    for kind, bad in ((0, igemm_n), (1, wgrad_n), (0, -1), (2, 0)):
+        with pytest.raises(_lib.Sy11Error):
+            _lib.tune_import(struct.pack("<Qii", 0xfeed0003, kind, bad))
