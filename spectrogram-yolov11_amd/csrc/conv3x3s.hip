@@ -137,25 +137,36 @@ __global__ __launch_bounds__(256, 2) void smallc3x3_kernel(const IgemmArgs a, co
           acc = ScMma<T>::run(wf[tt * CS + cs], xf, acc);
         }
       unsigned char* srow = stage + (gq * 32 + col) * ROWS + fb * 64 + half * 8;
+      typedef T t4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) {
-        typedef T t4 __attribute__((ext_vector_type(4)));
-        t4 o;
+      for (int e = 0; e < 16; ++e) {
+        const float v0 = ok ? acc[e] : 0.f;
+        acc[e] = v0;
+        s1[e] += v0;
+        s2[e] += v0 * v0;
+      }
+      if (plain) {                                    // training: statistics only — no branch inside the unrolled element loops
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int e = e4 * 4 + i;
-          const float v0 = ok ? acc[e] : 0.f;
-          s1[e] += v0;
-          s2[e] += v0 * v0;
-          float v = v0;
-          if (!plain) {                               // (inference / bias path: the bias comes from memory, not from 16 more registers)
-            const int n = fb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            if (a.bias && n < a.N) v += a.bias[n];
-            if (silu) v = silu_f(v);
-          }
-          o[i] = ElemTraits<T>::from_f(v);
+        for (int e4 = 0; e4 < 4; ++e4) {
+          t4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = ElemTraits<T>::from_f(acc[e4 * 4 + i]);
+          *(t4*)(srow + e4 * 16) = o;                 // filters fb*32 + 8*e4 + 4*half + (0..3)
         }
-        *(t4*)(srow + e4 * 16) = o;                                    // filters fb*32 + 8*e4 + 4*half + (0..3)
+      } else {                                        // inference: bias (from memory, not from 16 more registers) and SiLU
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          t4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = e4 * 4 + i, n = fb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            float v = acc[e];
+            if (a.bias) v += a.bias[min(n, a.N - 1)];
+            if (silu) v = silu_f(v);
+            o[i] = ElemTraits<T>::from_f(v);
+          }
+          *(t4*)(srow + e4 * 16) = o;
+        }
       }
     }
     __syncthreads();

@@ -1216,24 +1216,32 @@ __global__ __launch_bounds__(256) void stem_fwd_tile(const StemArgs a, const BnT
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         acc = StemMma<T>::run(wf[nt][0], af[0], acc);
         acc = StemMma<T>::run(wf[nt][1], af[1], acc);
+        typedef T t4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          typedef T t4 __attribute__((ext_vector_type(4)));
-          t4 o;
+        for (int e = 0; e < 16; ++e) {
+          s1[nt][e] += acc[e];
+          s2[nt][e] += acc[e] * acc[e];
+        }
+        if (plain) {                                  // training: no branch inside the unrolled element loops
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int e = e4 * 4 + i;
-            const float v0 = acc[e];
-            s1[nt][e] += v0;
-            s2[nt][e] += v0 * v0;
-            float v = v0;
-            if (!plain) {
-              v += bias_v[nt][e];
-              if (silu) v = silu_f(v);
-            }
-            o[i] = ElemTraits<T>::from_f(v);
+          for (int e4 = 0; e4 < 4; ++e4) {
+            t4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = ElemTraits<T>::from_f(acc[e4 * 4 + i]);
+            *(t4*)(srow + nt * 64 + e4 * 16) = o;     // channels nt*32 + 8*e4 + 4*half + (0..3)
           }
-          *(t4*)(srow + nt * 64 + e4 * 16) = o;       // channels nt*32 + 8*e4 + 4*half + (0..3)
+        } else {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            t4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float v = acc[e4 * 4 + i] + bias_v[nt][e4 * 4 + i];
+              if (silu) v = silu_f(v);
+              o[i] = ElemTraits<T>::from_f(v);
+            }
+            *(t4*)(srow + nt * 64 + e4 * 16) = o;
+          }
         }
       }
     }
