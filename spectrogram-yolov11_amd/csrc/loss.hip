@@ -222,9 +222,13 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float tss_inv) {
   __shared__ float red[3][16];
   const int grp = threadIdx.x >> 4, j = threadIdx.x & 15;
-  const long gi = (long)blockIdx.x * 16 + grp;
-  const bool live = gi < (long)a.B * a.A;
   float l_box = 0.f, l_cls = 0.f, l_dfl = 0.f;
+  // grid-stride over groups of 16 anchors (forward: <= 2048 workgroups, so that the three partial sums of a workgroup end in 6 K
+  // atomics per launch instead of 100 K onto the same 64 slots; backward: one group per workgroup, no sums)
+  const long BA = (long)a.B * a.A;
+  for (long base = (long)blockIdx.x * 16; base < BA; base += (long)gridDim.x * 16) {
+  const long gi = base + grp;
+  const bool live = gi < BA;
   if (live) {
     const int b = (int)(gi / a.A), an = (int)(gi - (long)b * a.A);
     int l, gx, gy;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float
       const float alpha = v / (v - iou + (1.f + eps));
       const float ciou = iou - (rho2 / cc + v * alpha);
       if (!BWD) {
-        if (j == 0) l_box = (1.f - ciou) * w;
+        if (j == 0) l_box += (1.f - ciou) * w;
       } else {
         // derivatives w.r.t. (px1, py1, px2, py2)
         const float diw[4] = {(iwr > 0.f && px1 > tx1) ? -1.f : 0.f, 0.f, (iwr > 0.f && px2 < tx2) ? 1.f : 0.f, 0.f};
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float
 #pragma unroll
       for (int s = 0; s < 4; ++s) drow[s * REG + j] = dlog[s];
     }
+  }
   }
   if (!BWD) {
 #pragma unroll
@@ -415,7 +420,8 @@ extern "C" int sy11_det_loss_terms(int32_t B, int32_t nc, int32_t nl, const floa
   if (rc) return rc;
   const long BA = (long)B * a.A;
   DetPartials dp;
-  const long nb = (BA + 15) / 16;
+  long nb = (BA + 15) / 16;
+  if (nb > 2048) nb = 2048;                          // grid-stride (see loss_terms_kernel)
   if (sy11_det(16)) {
     if (!dp.acquire((hipStream_t)stream, 1, nb, 4)) SY11_FAIL(SY11_ELAUNCH, "det_loss_terms: ordered-reduction workspace unavailable");
     a.sums = dp.buf(0); a.sum_slots = (int)nb;
