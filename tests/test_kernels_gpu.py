@@ -193,6 +193,75 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
         _lib.set_option("tune", tune0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 16, 20, 96, 32), (1, 32, 12, 160, 16), (2, 32, 9, 70, 24)])
+def test_few_channel_conv_epilogues_and_bf16(case, dtype):
+    """igemm configuration 19 (conv3x3s.hip) in both 16-bit types with every epilogue it takes: BN statistics (training), bias +
+    SiLU (the fused inference conv), accumulate (an input gradient added to an existing one), and into a channel slice of a wider
+    tensor (concat by pointer: y_ld > N, x_ld > C)."""
+    from sy11 import _lib
+    o = ops()
+    B, Cn, H, W, N = case
+    x = rnd(B, Cn, H, W, seed=41)
+    w = rnd(N, Cn, 3, 3, seed=42, scale=1.0 / math.sqrt(Cn * 9))
+    bias = rnd(N, seed=43, scale=0.5)
+    xq, wq = q(x, dtype), q(w, dtype)
+    wk = wq.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    ref = F.conv2d(xq, wq, None, 1, 1)
+    wide_x = torch.zeros(B, H, W, Cn + 16, dtype=dtype, device=DEV)
+    wide_x[..., 8:8 + Cn] = nhwc(x, dtype)
+    xv = wide_x[..., 8:8 + Cn]                                  # a channel slice: pixel stride Cn + 16
+    try:
+        _lib.set_option("igemm_cfg", 19)
+        wide_y = torch.full((B, H, W, N + 24), 7.0, dtype=dtype, device=DEV)
+        yv = wide_y[..., 16:16 + N]
+        ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+        o.conv2d_fwd(xv, wk, yv, 3, 1, 1, stats=(ssum, ssq))
+        close(to_nchw(yv), ref, dtype, "fwd into a slice")
+        assert bool((wide_y[..., :16] == 7.0).all()) and bool((wide_y[..., 16 + N:] == 7.0).all())      # neighbours untouched
+        close(ssum.cpu(), ref.sum((0, 2, 3)), dtype, "statistics", mult=4 * math.sqrt(B * H * W))
+        close(ssq.cpu(), (ref * ref).sum((0, 2, 3)), dtype, "statistics sq", mult=8)
+        y2 = torch.empty(B, H, W, N, dtype=dtype, device=DEV)
+        o.conv2d_fwd(xv, wk, y2, 3, 1, 1, bias=bias.to(DEV), silu=True)
+        close(to_nchw(y2), F.silu(ref + bias.view(1, -1, 1, 1)), dtype, "bias + SiLU", mult=2)
+        dy = rnd(B, N, H, W, seed=44)
+        ref_dx = torch.nn.grad.conv2d_input((B, Cn, H, W), wq, q(dy, dtype), 1, 1)
+        dx = torch.zeros(B, H, W, Cn, dtype=dtype, device=DEV)
+        wt = o.weight_transpose(wk)
+        o.conv2d_dgrad(nhwc(dy, dtype), wt, dx, (B, H, W, N), 3, 1, 1)
+        close(to_nchw(dx), ref_dx, dtype, "dgrad")
+        o.conv2d_dgrad(nhwc(dy, dtype), wt, dx, (B, H, W, N), 3, 1, 1, accumulate=True)
+        close(to_nchw(dx), 2 * ref_dx, dtype, "dgrad accumulate", mult=2)
+    finally:
+        _lib.set_option("igemm_cfg", -1)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 10, 80, 64), (1, 32, 8, 160, 16), (2, 128, 20, 20, 96), (1, 48, 12, 40, 72)])
+def test_patch_filter_gradient_bf16_and_slices(case):
+    """wgrad configurations 12-15 (wgrad3x3p_kernel) in bf16, on operands that are channel slices of wider tensors, with partial
+    32 / 64 blocks (C = 48, N = 72, 96); accumulates into dW."""
+    from sy11 import _lib
+    o = ops()
+    dtype = torch.bfloat16
+    B, Cn, H, W, N = case
+    x, dy = rnd(B, Cn, H, W, seed=51), rnd(B, N, H, W, seed=52)
+    ref = torch.nn.grad.conv2d_weight(q(x, dtype), (N, Cn, 3, 3), q(dy, dtype), 1, 1)
+    wide_x = torch.zeros(B, H, W, Cn + 8, dtype=dtype, device=DEV)
+    wide_x[..., 8:] = nhwc(x, dtype)
+    wide_dy = torch.zeros(B, H, W, N + 16, dtype=dtype, device=DEV)
+    wide_dy[..., :N] = nhwc(dy, dtype)
+    try:
+        for cfg in range(12, 16):
+            _lib.set_option("wgrad_cfg", cfg)
+            dw = torch.zeros(N, 3, 3, Cn, dtype=torch.float32, device=DEV)
+            o.conv2d_wgrad(wide_x[..., 8:], wide_dy[..., :N], dw, 3, 1, 1)
+            close(dw.cpu().permute(0, 3, 1, 2), ref, torch.float32, f"wgrad cfg {cfg}", mult=200)      # bf16 operands: 8 mantissa bits
+            o.conv2d_wgrad(wide_x[..., 8:], wide_dy[..., :N], dw, 3, 1, 1)
+            close(dw.cpu().permute(0, 3, 1, 2), 2 * ref, torch.float32, f"wgrad cfg {cfg} accumulate", mult=400)
+    finally:
+        _lib.set_option("wgrad_cfg", -1)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 32, 32, 96), (1, 32, 80, 80, 64), (1, 32, 31, 39, 64), (2, 256, 40, 40, 128), (3, 128, 32, 48, 32)])
 def test_stride2_input_gradient_all_parities_in_one_pass(case):
     """halo_dgrad_s2_kernel (conv3x3.hip): dx of a 3x3 / stride 2 / pad 1 conv, four parity classes from one dy patch, whole
