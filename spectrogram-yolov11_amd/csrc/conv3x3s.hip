@@ -280,8 +280,7 @@ int sy11_smallc3x3_launch(const IgemmArgs& a_in, int dtype, hipStream_t st) {
 #undef SY11_SCW
   SY11_LAUNCH_CHECK("smallc3x3");
   if (det) {
-    const int rc = dp.fold(0, a_in.stat_sum);
-    return rc ? rc : dp.fold(1, a_in.stat_sq);
+    return dp.fold01(a_in.stat_sum, a_in.stat_sq);
   }
   return SY11_OK;
 }

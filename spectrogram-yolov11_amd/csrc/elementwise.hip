@@ -357,8 +357,7 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
   });
   SY11_LAUNCH_CHECK("bn_act_bwd_reduce");
   if (det) {
-    const int rc = dp.fold(0, sum_g_out);
-    return rc ? rc : dp.fold(1, sum_gx_out);
+    return dp.fold01(sum_g_out, sum_gx_out);
   }
   return SY11_OK;
 }
@@ -927,11 +926,15 @@ extern "C" int sy11_bias_grad_cast(int32_t dtype, int64_t M, int32_t N, int32_t 
 // with gridDim.y == 1).  Block = 64 columns x 4 row lanes; lane q adds rows q, q + 4, ... of its 64-row group in order, the four
 // lanes are folded in index order: a fixed tree, whatever the launch timing.
 template <bool ACCUM>
-__global__ __launch_bounds__(256) void fold_stage_kernel(long rows, int N, const float* __restrict__ src, long stride, float* __restrict__ dst, long group) {
+__global__ __launch_bounds__(256) void fold_stage_kernel(long rows, int N, const float* __restrict__ src, long stride, float* __restrict__ dst, long group,
+                                                         long src_bstride, long dst_bstride, float* __restrict__ dst1) {
+  // blockIdx.z = buffer (two statistic buffers of one launch fold side by side: the same tree per buffer as two separate folds)
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const long r0 = (long)blockIdx.y * group, r1 = r0 + group < rows ? r0 + group : rows;
+  src += (long)blockIdx.z * src_bstride;
+  float* out = ACCUM ? (blockIdx.z ? dst1 : dst) : dst + (long)blockIdx.z * dst_bstride;
   float t = 0.f;
   if (c < N)
     for (long r = r0 + q; r < r1; r += 4) t += src[r * stride + c];
@@ -939,8 +942,26 @@ __global__ __launch_bounds__(256) void fold_stage_kernel(long rows, int N, const
   __syncthreads();
   if (q == 0 && c < N) {
     const float tot = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
-    if (ACCUM) dst[c] += tot; else dst[(long)blockIdx.y * N + c] = tot;
+    if (ACCUM) out[c] += tot; else out[(long)blockIdx.y * N + c] = tot;
   }
+}
+// the two buffers of a DetPartials block ([2][rows][N], `scratch` twice sy11_fold_scratch_floats) in one launch per stage
+int sy11_fold_rows_ordered2(long rows, int N, const float* partials, long stride, long buf_stride, float* out0, float* out1, float* scratch,
+                            hipStream_t st) {
+  if (rows <= 0 || N <= 0) return SY11_OK;
+  const float* src = partials;
+  long sstride = stride, sb = buf_stride;
+  float* ping = scratch;
+  while (rows > 256) {
+    const long nr = (rows + 63) / 64;
+    float* dst = ping;
+    hipLaunchKernelGGL((fold_stage_kernel<false>), dim3(cdiv(N, 64), (unsigned)nr, 2), dim3(256), 0, st, rows, N, src, sstride, dst, 64L, sb, nr * N, (float*)nullptr);
+    src = dst; sstride = N; sb = nr * N; rows = nr;
+    ping = dst + 2 * nr * N;
+  }
+  hipLaunchKernelGGL((fold_stage_kernel<true>), dim3(cdiv(N, 64), 1, 2), dim3(256), 0, st, rows, N, src, sstride, out0, rows, sb, 0L, out1);
+  SY11_LAUNCH_CHECK("fold_rows2");
+  return SY11_OK;
 }
 int sy11_fold_rows_ordered(long rows, int N, const float* partials, long stride, float* out, float* scratch, hipStream_t st) {
   if (rows <= 0 || N <= 0) return SY11_OK;
@@ -950,11 +971,11 @@ int sy11_fold_rows_ordered(long rows, int N, const float* partials, long stride,
   while (rows > 256) {                                   // 64 rows -> 1 per stage until one workgroup column can finish
     const long nr = (rows + 63) / 64;
     float* dst = ping;
-    hipLaunchKernelGGL((fold_stage_kernel<false>), dim3(cdiv(N, 64), (unsigned)nr), dim3(256), 0, st, rows, N, src, sstride, dst, 64L);
+    hipLaunchKernelGGL((fold_stage_kernel<false>), dim3(cdiv(N, 64), (unsigned)nr), dim3(256), 0, st, rows, N, src, sstride, dst, 64L, 0L, 0L, (float*)nullptr);
     src = dst; sstride = N; rows = nr;
     ping = dst + nr * N;                                 // next stage writes behind this one (scratch holds rows/64 + 64 rows)
   }
-  hipLaunchKernelGGL((fold_stage_kernel<true>), dim3(cdiv(N, 64), 1), dim3(256), 0, st, rows, N, src, sstride, out, rows);
+  hipLaunchKernelGGL((fold_stage_kernel<true>), dim3(cdiv(N, 64), 1), dim3(256), 0, st, rows, N, src, sstride, out, rows, 0L, 0L, (float*)nullptr);
   SY11_LAUNCH_CHECK("fold_rows");
   return SY11_OK;
 }

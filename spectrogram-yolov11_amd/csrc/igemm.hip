@@ -612,8 +612,7 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
 #undef SY11_IG
   SY11_LAUNCH_CHECK("igemm");
   if (det) {
-    const int rc = dp.fold(0, stat_sum_out);
-    return rc ? rc : dp.fold(1, stat_sq_out);
+    return dp.fold01(stat_sum_out, stat_sq_out);
   }
   return SY11_OK;
 }

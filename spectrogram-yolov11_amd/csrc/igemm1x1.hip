@@ -267,8 +267,7 @@ int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, floa
 #undef SY11_P1
   SY11_LAUNCH_CHECK("igemm1x1p");
   if (det) {
-    const int rc = dp.fold(0, stat_sum);
-    return rc ? rc : dp.fold(1, stat_sq);
+    return dp.fold01(stat_sum, stat_sq);
   }
   return SY11_OK;
 }

@@ -31,6 +31,13 @@ struct WgradArgs {
   signed char tap_dx[64];
 };
 
+// dW element of a finished tile: f32 atomic add (pixel splits meet in dW), or — ordered mode, where split s owns its own partial dW
+// and every element of it has exactly ONE writer — a plain store (no zero fill of the partials, no atomics)
+template <bool STORE>
+__device__ __forceinline__ void dw_out(float* p, float v) {
+  if (STORE) *p = v; else atomicAdd(p, v);
+}
+
 template <typename T>
 __device__ __forceinline__ void load_chunk_f32(const T* p, float* out);
 template <>
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wr * (TILE / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         const int k = k0 + wc * (TILE / 2) + j * 32 + fcol;
-        if (n < a.N && k < a.K) atomicAdd(dwp + (long)n * a.K + k, acc[i][j][e]);
+        if (n < a.N && k < a.K) { if (a.dw_split_stride) dw_out<true>(dwp + (long)n * a.K + k, acc[i][j][e]); else dw_out<false>(dwp + (long)n * a.K + k, acc[i][j][e]); }
       }
 }
 
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
     for (int e = 0; e < 16; ++e) {
       const int n = n0 + fi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
       const int k = k0 + fj * 32 + fcol;
-      if (n < a.N && k < a.K) atomicAdd(dwp + (long)n * a.K + k, tot[e]);
+      if (n < a.N && k < a.K) { if (a.dw_split_stride) dw_out<true>(dwp + (long)n * a.K + k, tot[e]); else dw_out<false>(dwp + (long)n * a.K + k, tot[e]); }
     }
     return;
   }
@@ -368,7 +375,10 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < FI; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) atomicAdd(base + (long)(i * 32 + (e & 3) + 8 * (e >> 2)) * a.K + j * 32, acc[i][j][e]);
+        for (int e = 0; e < 16; ++e) {
+          float* p = base + (long)(i * 32 + (e & 3) + 8 * (e >> 2)) * a.K + j * 32;
+          if (a.dw_split_stride) dw_out<true>(p, acc[i][j][e]); else dw_out<false>(p, acc[i][j][e]);
+        }
     return;
   }
 #pragma unroll
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wr * (TILE / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         const int k = k0 + wc * (TILE / 2) + j * 32 + fcol;
-        if (n < a.N && k < a.K) atomicAdd(dwp + (long)n * a.K + k, acc[i][j][e]);
+        if (n < a.N && k < a.K) { if (a.dw_split_stride) dw_out<true>(dwp + (long)n * a.K + k, acc[i][j][e]); else dw_out<false>(dwp + (long)n * a.K + k, acc[i][j][e]); }
       }
 }
 
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(256, SP == 80 ? 4 : 2) void wgrad3x3p_kernel(const 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int dn = (e & 3) + 8 * (e >> 2);
-        if (nr + dn < a.N) atomicAdd(base + (long)dn * a.K + t * a.C, acc[t][e]);
+        if (nr + dn < a.N) { if (a.dw_split_stride) dw_out<true>(base + (long)dn * a.K + t * a.C, acc[t][e]); else dw_out<false>(base + (long)dn * a.K + t * a.C, acc[t][e]); }
       }
   }
 }
@@ -621,7 +631,8 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   float* const dw_out = a.dw;
   const bool det = sy11_det(8) && splits > 1;
   if (det) {
-    if (!dp.acquire(st, 1, splits, a.N * a.K)) SY11_FAIL(SY11_ELAUNCH, "conv2d_wgrad: ordered-reduction workspace unavailable (%d x %d floats)", splits, a.N * a.K);
+    // every element of a split's partial dW has exactly one writer (plain stores in the kernels): no zero fill
+    if (!dp.acquire(st, 1, splits, a.N * a.K, false)) SY11_FAIL(SY11_ELAUNCH, "conv2d_wgrad: ordered-reduction workspace unavailable (%d x %d floats)", splits, a.N * a.K);
     a.dw = dp.buf(0);
     a.dw_split_stride = (long)a.N * a.K;
   }
