@@ -317,11 +317,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long M, int C, const
   }
   // dense atomics: lane t adds channel (cbase + t) -> one 256-byte request group per 64 lanes instead of VEC-strided scalars
   // (same-line atomic REQUESTS, not bytes, are what the memory side serialises)
+  // ordered mode: one row per workgroup x (slots == gridDim.x), every element of it written by exactly one workgroup (x, y): plain
+  // stores, and the host skips the zero fill
+  const bool exclusive = slots == (int)gridDim.x && slots > 1;
   for (int e = threadIdx.x; e < l.nch; e += 256) {
     const int cl2 = e / VEC, i2 = e - cl2 * VEC;
     const long ch = (long)(blockIdx.x % slots) * C + l.cbase + e;
-    atomicAdd(sum_g + ch, red[0][cl2][i2]);
-    atomicAdd(sum_gx + ch, red[1][cl2][i2] * rstd[l.cbase + e]);
+    const float g0 = red[0][cl2][i2], g1 = red[1][cl2][i2] * rstd[l.cbase + e];
+    if (exclusive) { sum_g[ch] = g0; sum_gx[ch] = g1; }
+    else { atomicAdd(sum_g + ch, g0); atomicAdd(sum_gx + ch, g1); }
   }
 }
 
@@ -347,7 +351,7 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
   float* const sum_gx_out = sum_gx;
   const bool det = sy11_det(4) && w.grid > 1;
   if (det) {
-    if (!dp.acquire(st, 2, w.grid, C)) SY11_FAIL(SY11_ELAUNCH, "bn_act_bwd_reduce: ordered-reduction workspace unavailable");
+    if (!dp.acquire(st, 2, w.grid, C, false)) SY11_FAIL(SY11_ELAUNCH, "bn_act_bwd_reduce: ordered-reduction workspace unavailable");   // rows are stored whole: no zero fill
     sum_g = dp.buf(0); sum_gx = dp.buf(1); slots = w.grid;
   }
   SY11_DISPATCH_DTYPE(dtype, T, {
