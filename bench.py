@@ -45,7 +45,7 @@ FAMILIES = {
     "conv fwd+dgrad (dense)": {"calls": ("sy11_conv2d_fwd", "sy11_conv2d_dgrad"), "symbols": ("igemm_kernel", "igemm1x1p_kernel", "halo3x3_kernel", "halo_dgrad_s2_kernel", "smallc3x3_kernel")},
     "conv wgrad (dense)": {"calls": ("sy11_conv2d_wgrad",), "symbols": ("wgrad16_kernel", "wgrad3x3p_kernel", "wgrad_kernel")},
     "depthwise conv": {"calls": (), "symbols": ("dw3x3_kernel", "dwconv_")},
-    "batchnorm": {"calls": ("sy11_bn_act_fwd", "sy11_bn_act_bwd_reduce", "sy11_bn_act_bwd_apply", "sy11_bn_finalize"),
+    "batchnorm": {"calls": ("sy11_bn_act_fwd", "sy11_bn_act_bwd_reduce", "sy11_bn_act_bwd_apply", "sy11_bn_act_bwd_apply_res", "sy11_bn_finalize"),
                   "symbols": ("bn_act_fwd_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "bn_finalize_kernel")},
     "stem": {"calls": ("sy11_stem_conv_fwd", "sy11_stem_conv_wgrad"), "symbols": ("stem_fwd_tile", "stem_wgrad_tile", "stem_fwd_mma", "stem_wgrad_mma")},
 }

@@ -164,6 +164,15 @@ int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, in
                           const float* sum_gx, int32_t sum_slots, void* dy, int32_t dy_ld, float* dgamma, float* dbeta,
                           void* stream);
 
+/* pass 2 with the gradient of a RESIDUAL operand folded in (Bottleneck shortcut, nn/modules/block.py:725: z = x + act(bn(conv))):
+ * res_grad[m, 0:C] (= | +=, f32 add and one rounding as sy11_copy2d) dz[m, 0:C], from the dz values the pass holds anyway —
+ * instead of a separate three-pass copy launch.  res_grad == NULL: exactly sy11_bn_act_bwd_apply.                              */
+int sy11_bn_act_bwd_apply_res(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
+                              int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
+                              const float* shift, const float* gamma, int32_t silu, const float* sum_g,
+                              const float* sum_gx, int32_t sum_slots, void* dy, int32_t dy_ld, float* dgamma, float* dbeta,
+                              void* res_grad, int32_t res_ld, int32_t res_accumulate, void* stream);
+
 /* ---- data movement inside the graph --------------------------------------------------------------------- */
 /* dst[m, 0:C] (= | +=) src[m, 0:C] with independent pixel strides: torch.cat / chunk (conv.py:1821,
  * block.py:466-468) and residual-gradient accumulation.                                                     */

@@ -367,13 +367,17 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
 }
 
 // pass 2: dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M) = k0*g - k1 - (y - mean)*k2; block (0,*) also accumulates dgamma/dbeta
-template <typename T, int VEC, bool SILU>
+// RES: the layer's output was also a residual sum (Bottleneck shortcut, block.py:725): the gradient of the residual operand is dz
+// itself — written (or added, f32 add, one rounding: what sy11_copy2d's accumulate does) from the dz values this pass holds anyway,
+// instead of a separate three-pass copy launch
+template <typename T, int VEC, bool SILU, bool RES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const T* __restrict__ y, int y_ld, const T* __restrict__ dz, int dz_ld,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                            const float* __restrict__ sum_gx, T* __restrict__ dy, int dy_ld, float* dgamma,
-                                                           float* dbeta, int cpv, int rows_pb, int slots, const RowWalk w) {
+                                                           float* dbeta, int cpv, int rows_pb, int slots, const RowWalk w, T* resg, int resg_ld,
+                                                           int resg_acc) {
   constexpr int U = 4;
   const RowLane l = row_lane<VEC>(cpv, rows_pb);
   float* s_sc = s_coef;
@@ -426,6 +430,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const 
   coef_get<VEC>(s_k1, l.cl * VEC, k1);
   coef_get<VEC>(s_k2, l.cl * VEC, k2);
   while (m < mend) {
+    if (RES) {
+      float vr[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long mm = m + u * w.us < mend ? m + u * w.us : mend - 1;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) vr[u][i] = 0.f;
+        if (resg_acc) vload<T, VEC>(resg + mm * resg_ld + l.c, vr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) vr[u][i] += vg[u][i];
+        if (m + u * w.us < mend) vstore<T, VEC>(resg + (m + u * w.us) * resg_ld + l.c, vr[u]);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -441,17 +461,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, const 
   }
 }
 
-#define SY11_BNA(VV, SS) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VV, SS>), grid, block, coef_bytes(g, VV, 6), st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb, sum_slots > 1 ? sum_slots : 1, w)
+#define SY11_BNA(VV, SS)                                                                                                                         \
+  do {                                                                                                                                          \
+    if (res_grad) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VV, SS, true>), grid, block, coef_bytes(g, VV, 6), st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb, sum_slots > 1 ? sum_slots : 1, w, (T*)res_grad, res_ld, res_accumulate); \
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VV, SS, false>), grid, block, coef_bytes(g, VV, 6), st, (long)M, C, (const T*)y, y_ld, (const T*)dz, dz_ld, mean, rstd, scale, shift, gamma, sum_g, sum_gx, (T*)dy, dy_ld, dgamma, dbeta, g.cpv, g.rows_pb, sum_slots > 1 ? sum_slots : 1, w, (T*)nullptr, 0, 0); \
+  } while (0)
+extern "C" int sy11_bn_act_bwd_apply_res(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
+                                         int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
+                                         const float* shift, const float* gamma, int32_t silu, const float* sum_g,
+                                         const float* sum_gx, int32_t sum_slots, void* dy, int32_t dy_ld, float* dgamma, float* dbeta,
+                                         void* res_grad, int32_t res_ld, int32_t res_accumulate, void* stream);
 extern "C" int sy11_bn_act_bwd_apply(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
                                      int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
                                      const float* shift, const float* gamma, int32_t silu, const float* sum_g,
                                      const float* sum_gx, int32_t sum_slots, void* dy, int32_t dy_ld, float* dgamma, float* dbeta,
                                      void* stream) {
+  return sy11_bn_act_bwd_apply_res(dtype, M, C, y, y_ld, dz, dz_ld, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, sum_slots, dy, dy_ld,
+                                   dgamma, dbeta, nullptr, 0, 0, stream);
+}
+extern "C" int sy11_bn_act_bwd_apply_res(int32_t dtype, int64_t M, int32_t C, const void* y, int32_t y_ld, const void* dz,
+                                         int32_t dz_ld, const float* mean, const float* rstd, const float* scale,
+                                         const float* shift, const float* gamma, int32_t silu, const float* sum_g,
+                                         const float* sum_gx, int32_t sum_slots, void* dy, int32_t dy_ld, float* dgamma, float* dbeta,
+                                         void* res_grad, int32_t res_ld, int32_t res_accumulate, void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && M > 0 && C > 0 && y && dz && dy && mean && rstd && scale && shift && gamma && sum_g && sum_gx, "bn_act_bwd_apply: bad argument");
+  SY11_REQUIRE(!res_grad || (res_ld >= C && res_grad != dz && res_grad != dy), "bn_act_bwd_apply: residual gradient needs its own buffer and a pixel stride >= C");
   SY11_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_act_bwd_apply: dgamma/dbeta both or neither");
   SY11_REQUIRE(y_ld >= C && dz_ld >= C && dy_ld >= C, "bn_act_bwd_apply: pixel stride < C");
   const int esz = dtype_size(dtype);
-  const bool v = vec_ok(esz, C, {y_ld, dz_ld, dy_ld}, {y, dz, dy});
+  const bool v = vec_ok(esz, C, {y_ld, dz_ld, dy_ld, res_grad ? res_ld : y_ld}, {y, dz, dy, res_grad ? res_grad : y});
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
   // the slot fold of the prologue is paid per block (C x slots x 2 loads): two trips per block on the big maps; on small maps with
   // many channels (20x20x512: the fold reads as many bytes as a two-trip block streams) four or eight

@@ -61,6 +61,8 @@ SIGNATURES = {
     "sy11_bn_act_bwd_reduce": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp],
     "sy11_bn_act_bwd_apply": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                               _vp, _i32, _vp, _vp, _vp],
+    "sy11_bn_act_bwd_apply_res": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
+                                  _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "sy11_copy2d": [_i32, _i64, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
     "sy11_upsample2x_fwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp],
     "sy11_upsample2x_bwd": [_i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp],

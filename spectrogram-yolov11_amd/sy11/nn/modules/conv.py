@@ -223,11 +223,11 @@ class Conv(nn.Module):
                 ops.bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, silu, sg[0], sg[1])
                 dy = torch.empty_like(y)
                 has_bn = id(bn.weight) in gs.views
+                rg, acc = res.grad_for_write() if (res is not None and res.req) else (None, False)
+                # the residual operand's gradient is dz itself: written / added by the apply pass from the values it holds
                 ops.bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, silu, sg[0], sg[1], dy,
-                                     gs.grad_vec(bn.weight) if has_bn else None, gs.grad_vec(bn.bias) if has_bn else None)
-                if res is not None and res.req:
-                    rg, acc = res.grad_for_write()
-                    ops.copy2d(dz, rg, accumulate=acc)
+                                     gs.grad_vec(bn.weight) if has_bn else None, gs.grad_vec(bn.bias) if has_bn else None,
+                                     res_grad=rg, res_accumulate=acc)
                 if id(conv.weight) in gs.views:
                     dw = gs.grad_krsc(conv.weight)
                     if stem:

@@ -213,13 +213,21 @@ def bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, silu, sum_g, sum_gx):
          _p(scale), _p(shift), int(silu), _p(sum_g), _p(sum_gx), slots, _stream())
 
 
-def bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, dy, dgamma, dbeta):
+def bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, silu, sum_g, sum_gx, dy, dgamma, dbeta, res_grad=None, res_accumulate=False):
+    """``res_grad``: gradient buffer of a residual operand of the layer's output (same pixels, own stride): (= | +=) dz in the same pass."""
     M, Cn = _mc(y)
     _stream_meta("bn_bwd_apply", M, Cn, y, dz, dy)
     slots = sum_g.shape[0] if sum_g.dim() == 2 else 1
-    call("sy11_bn_act_bwd_apply", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
+    if res_grad is None:
+        call("sy11_bn_act_bwd_apply", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
+             _p(scale), _p(shift), _p(gamma), int(silu), _p(sum_g), _p(sum_gx), slots, _p(dy), view_ld(dy), _p(dgamma),
+             _p(dbeta), _stream())
+        return
+    if res_grad.dtype != y.dtype or tuple(res_grad.shape) != tuple(y.shape):
+        raise _lib.Sy11Error("bn_act_bwd_apply: the residual gradient must have the layer's shape and dtype")
+    call("sy11_bn_act_bwd_apply_res", dt_code(y.dtype), M, Cn, _p(y), view_ld(y), _p(dz), view_ld(dz), _p(mean), _p(rstd),
          _p(scale), _p(shift), _p(gamma), int(silu), _p(sum_g), _p(sum_gx), slots, _p(dy), view_ld(dy), _p(dgamma),
-         _p(dbeta), _stream())
+         _p(dbeta), _p(res_grad), view_ld(res_grad), int(bool(res_accumulate)), _stream())
 
 
 def bias_grad_cast(dz, dy, dbias=None, partials=None):

@@ -417,6 +417,38 @@ def test_batchnorm_silu_fwd_bwd(Cn, silu, dtype):
     close(to_nchw(dyv), yr.grad, dtype, "bn dy", mult=6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("Cn,B,H,W", [(136, 3, 37, 41), (24, 5, 61, 67), (64, 16, 80, 80), (2056, 2, 9, 11)])
+def test_batchnorm_backward_apply_writes_the_residual_gradient(Cn, B, H, W, accumulate, dtype):
+    """sy11_bn_act_bwd_apply_res: dy as without the residual output, and res_grad (= | +=) dz bit-identical to what the separate
+    sy11_copy2d launch produced (f32 add, one rounding), into a channel slice of a wider buffer."""
+    o = ops()
+    M = B * H * W
+    y, dz = rnd(B, Cn, H, W, seed=61, scale=1.5), rnd(B, Cn, H, W, seed=62)
+    gamma, beta = 1 + 0.3 * rnd(Cn, seed=63), 0.2 * rnd(Cn, seed=64)
+    f = lambda t: t.to(DEV)
+    yv, dzv = nhwc(y, dtype), nhwc(dz, dtype)
+    ssum, ssq = yv.float().sum((0, 1, 2)), (yv.float() ** 2).sum((0, 1, 2))
+    mean, rstd, scale, shift = (torch.empty(Cn, device=DEV) for _ in range(4))
+    o.bn_finalize(M, ssum, ssq, f(gamma), f(beta), 1e-3, 0.03, None, None, mean, rstd, scale, shift)
+    sg = torch.zeros(2, 8, Cn, device=DEV)
+    o.bn_act_bwd_reduce(yv, dzv, mean, rstd, scale, shift, True, sg[0], sg[1])
+    old = nhwc(rnd(B, Cn, H, W, seed=65), dtype)
+    wide = torch.full((B, H, W, Cn + 8), 3.0, dtype=dtype, device=DEV)
+    wide[..., :Cn] = old
+    ref_dy = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    o.bn_act_bwd_apply(yv, dzv, mean, rstd, scale, shift, f(gamma), True, sg[0], sg[1], ref_dy, None, None)
+    ref_res = old.clone()
+    o.copy2d(dzv, ref_res, accumulate=accumulate)
+    dy = torch.empty_like(ref_dy)
+    o.bn_act_bwd_apply(yv, dzv, mean, rstd, scale, shift, f(gamma), True, sg[0], sg[1], dy, None, None,
+                       res_grad=wide[..., :Cn], res_accumulate=accumulate)
+    assert torch.equal(dy, ref_dy)
+    assert torch.equal(wide[..., :Cn], ref_res)
+    assert bool((wide[..., Cn:] == 3.0).all())
+
+
 @pytest.mark.parametrize("row_map", [0, 1])
 @pytest.mark.parametrize("Cn,B,H,W,slots", [(136, 3, 37, 41, 8), (2056, 2, 9, 11, 1), (24, 5, 61, 67, 8), (64, 16, 80, 80, 8)])
 def test_batchnorm_row_walk(Cn, B, H, W, slots, row_map):
