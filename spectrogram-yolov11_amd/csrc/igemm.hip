@@ -151,10 +151,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   // captured by reference next to the "memory"-clobbering DMA asm they were kept in scratch memory (r02 ISA inspection:
   // two scratch_load_dword + s_waitcnt vmcnt(0) at the top of every stage — a ~400-cycle stall in front of each DMA issue
   // that also drained every LDS-DMA still in flight, so deeper rings could not help)
-  struct KPos { int kt, kc; };
+  // xo / wo: the tap's byte deltas (LDS table) of THIS position, read one stage ahead — at the end of the previous issue — so that the
+  // table's LDS round trip hides behind a stage of MFMAs instead of sitting in front of every stage's DMA issue (r03)
+  struct KPos { int kt, kc, xo, wo; };
   KPos kp;
   kp.kt = (ld_chunk * EPC) / a.C;
   kp.kc = (ld_chunk * EPC) - kp.kt * a.C;
+  kp.xo = kp.wo = 0;
   const dma_rsrc_t xr = make_dma_rsrc(a.x, a.x_bytes), wr_ = make_dma_rsrc(a.w, a.w_bytes);
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -166,6 +169,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   const int bpol = __builtin_amdgcn_readfirstlane(a.bpol);
   const bool b_issue = (BN >= RPP) || (wave_u * RPI < BN);         // BN < rows-per-pass: only waves covering real rows issue
   __syncthreads();  // tap tables visible
+  {
+    const int tt0 = kp.kt < a.T ? kp.kt : 0;
+    kp.xo = s_tapoff[tt0];
+    kp.wo = s_tapoff[64 + tt0];
+  }
 
   auto issue_stage = [&](int stage_idx, KPos k) -> KPos {
     int kt = k.kt, kc = k.kc;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
     const unsigned sb = sa + A_BYTES;
     const bool kvalid = kt < a.T;
     const int tt = kvalid ? kt : 0;
-    const int xo = s_tapoff[tt] + kc * ESZ, wo = s_tapoff[64 + tt] + kc * ESZ;
+    const int xo = k.xo + kc * ESZ, wo = k.wo + kc * ESZ;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const bool ok = kvalid && ((a_mask[i] >> tt) & 1ull);
@@ -206,6 +214,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
     }
     KPos r;
     r.kt = kt; r.kc = kc;
+    const int tn = kt < a.T ? kt : 0;
+    r.xo = s_tapoff[tn];
+    r.wo = s_tapoff[64 + tn];
     return r;
   };
 
