@@ -199,21 +199,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void h
         issue_a(t * CH, (t + 1) * CH < NAW ? (t + 1) * CH : NAW, slab + 1);
       }
       const unsigned char* sBc = smem + 2 * A_BYTES + ((slab + t) & 3) * B_BYTES;
+      // all fragment reads of the stage (both k-groups) before its MFMAs: read - wait - MFMA per fragment exposed the LDS round
+      // trip 3-4 times per stage of only 2 MI NI MFMAs (r03 ISA inspection; the order is pinned, the allocator would fold the sets)
+      uint4 fa[2][MI], fb[2][NI];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        uint4 fa[MI], fb[NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const int row = arow0[i] + toff[t];
-          fa[i] = *(const uint4*)(sAc + row * KB + (((2 * g + fh) ^ ((row >> 2) & 3)) << 4));
+          fa[g][i] = *(const uint4*)(sAc + row * KB + (((2 * g + fh) ^ ((row >> 2) & 3)) << 4));
         }
 #pragma unroll
-        for (int j = 0; j < NI; ++j) fb[j] = *(const uint4*)(sBc + fb_off[j][g]);
+        for (int j = 0; j < NI; ++j) fb[g][j] = *(const uint4*)(sBc + fb_off[j][g]);
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j) h_mma(fa[i], fb[j], acc[i][j]);
-      }
+          for (int j = 0; j < NI; ++j) h_mma(fa[g][i], fb[g][j], acc[i][j]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI * NI, 0);
     }
   }
   __syncthreads();                                   // all fragment reads done before the epilogue reuses the operand buffers
@@ -514,15 +520,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void h
       }
       const unsigned char* sBc = smem + 2 * A_BYTES + ((slab + t) & 3) * B_BYTES;
       const int row = arow0 + AY[t] * PW + AX[t];
+      uint4 fa[2], fb[2][NI];                         // all fragment reads of the stage first (see halo3x3_kernel)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const uint4 fa = *(const uint4*)(sAc + row * KB + (((2 * g + fh) ^ ((row >> 2) & 3)) << 4));
+        fa[g] = *(const uint4*)(sAc + row * KB + (((2 * g + fh) ^ ((row >> 2) & 3)) << 4));
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const uint4 fb = *(const uint4*)(sBc + fb_off[j][g]);
-          h_mma(fa, fb, acc[CLS[t]][j]);
-        }
+        for (int j = 0; j < NI; ++j) fb[g][j] = *(const uint4*)(sBc + fb_off[j][g]);
       }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) h_mma(fa[g], fb[g][j], acc[CLS[t]][j]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (1 + NI), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI, 0);
     }
   }
   __syncthreads();
