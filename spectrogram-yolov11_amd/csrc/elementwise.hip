@@ -7,6 +7,16 @@
 #include "common.h"
 #include "tune.h"
 #include "det.h"
+#include <type_traits>
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sy11_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sy11_static_for<I + 1, N>(f);
+  }
+}
+
 
 template <typename T, int VEC> struct Vec {
   T v[VEC];
@@ -760,6 +770,89 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(int B, int H, int W, 
     }
   }
 }
+// Separable form for 16-bit inputs with 16-byte channel vectors (r03): the (value, window position) key of maxpool5_fwd_kernel is a
+// maximum of integers, so the 5 x 5 window splits into a row pass (5 keys per pixel, low bits 5 - wx) and a column pass over five
+// row results (+ 5 (4 - wy)): 10 key operations and — with a thread walking R consecutive rows of one column — (R + 4) x 5 / R loads
+// per output instead of 25 and 25.  Out-of-image positions load a clamped duplicate whose key has smaller low bits than its legal
+// twin (0 for an illegal row, 5 (4 - wy) for an illegal column in a legal row), so they never win: the result key, hence value and
+// argmax, is bit-identical to the 25-way form.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void maxpool5_fwd_sep_kernel(int B, int H, int W, int C, const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld,
+                                                               uint8_t* __restrict__ idx, int cpv, int bands, long total) {
+  constexpr int VEC = 8;
+  static_assert(sizeof(T) == 2, "16-bit inputs");
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int cv = (int)(gid % cpv);
+  long q = gid / cpv;
+  const int w = (int)(q % W); q /= W;
+  const int band = (int)(q % bands);
+  const int b = (int)(q / bands);
+  const int h0 = band * R, c = cv * VEC;
+  const T* xb = x + ((long)b * H * W) * x_ld + c;
+  unsigned cmask = 0;
+  int ixs[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    cmask |= ((unsigned)(w + k - 2) < (unsigned)W ? 1u : 0u) << k;
+    ixs[k] = min(max(w + k - 2, 0), W - 1);
+  }
+  auto row_pass = [&](int r, int (&kr)[VEC]) {            // r: window row index relative to h0 - 2
+    const int iy = min(max(h0 - 2 + r, 0), H - 1);
+    float v[5][VEC];
+#pragma unroll
+    for (int wx = 0; wx < 5; ++wx) vload<T, VEC>(xb + ((long)iy * W + ixs[wx]) * x_ld, v[wx]);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) kr[i] = (int)0x80000000;
+#pragma unroll
+    for (int wx = 0; wx < 5; ++wx) {
+      const int low = (int)((cmask >> wx) & 1u) * (5 - wx);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const int bits = __builtin_bit_cast(int, v[wx][i]);
+        const int k = (bits ^ ((bits >> 31) & 0x7fffffe0)) + low;
+        kr[i] = k > kr[i] ? k : kr[i];
+      }
+    }
+  };
+  int kr[R + 4][VEC];
+#pragma unroll
+  for (int r = 0; r < R + 4; ++r) row_pass(r, kr[r]);
+#pragma unroll
+  for (int o = 0; o < R; ++o) {
+    const int h = h0 + o;
+    if (h >= H) break;
+    int key[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) key[i] = (int)0x80000000;
+#pragma unroll
+    for (int wy = 0; wy < 5; ++wy) {
+      const bool rok = (unsigned)(h + wy - 2) < (unsigned)H;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const int k = rok ? kr[o + wy][i] + 5 * (4 - wy) : (kr[o + wy][i] & ~31);
+        key[i] = k > key[i] ? k : key[i];
+      }
+    }
+    float best[VEC];
+    unsigned bi[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      bi[i] = (unsigned)(25 - (key[i] & 31));
+      const int ob = key[i] & ~31;
+      best[i] = __builtin_bit_cast(float, ob ^ ((ob >> 31) & 0x7fffffe0));
+    }
+    const long m = ((long)b * H + h) * W + w;
+    vstore<T, VEC>(y + m * y_ld + c, best);
+    if (idx) {
+      uint2 pk;
+      pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *(uint2*)(idx + m * C + c) = pk;
+    }
+  }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(int B, int H, int W, int C, const T* __restrict__ dy, int dy_ld,
                                                            const uint8_t* __restrict__ idx, T* __restrict__ dx, int dx_ld, int accumulate,
@@ -812,6 +905,78 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(int B, int H, int W, 
   }
 }
 
+// Backward with the same walk (16-bit, 16-byte channel vectors, r03): a thread owns R consecutive rows of one column; the (dy, argmax)
+// pairs of the five window rows around the current output row live in a ring of 5 x 5 register slots, so every row of pairs is loaded
+// ONCE per thread ((R + 4) x 5 / R pairs per output instead of 25).  Same sum, same order (window rows top to bottom, columns left to
+// right) as maxpool5_bwd_kernel: bit-identical.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void maxpool5_bwd_walk_kernel(int B, int H, int W, int C, const T* __restrict__ dy, int dy_ld,
+                                                                const uint8_t* __restrict__ idx, T* __restrict__ dx, int dx_ld, int accumulate,
+                                                                int cpv, int bands, long total) {
+  constexpr int VEC = 8;
+  static_assert(sizeof(T) == 2, "16-bit inputs");
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int cv = (int)(gid % cpv);
+  long q = gid / cpv;
+  const int w = (int)(q % W); q /= W;
+  const int band = (int)(q % bands);
+  const int b = (int)(q / bands);
+  const int h0 = band * R, c = cv * VEC;
+  const long img = (long)b * H * W;
+  bool cok[5];
+  int ixs[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    cok[k] = (unsigned)(w + k - 2) < (unsigned)W;
+    ixs[k] = cok[k] ? w + k - 2 : w;                     // an illegal window column loads the pixel's own column (never selected)
+  }
+  uint4 g[5][5];                                        // ring slot (window row mod 5) x window column: 8 gradient values
+  uint2 pi[5][5];                                       //                                                  8 argmax bytes
+  sy11_static_for<0, R + 4>([&](auto s_c) {             // a compile-time step index: the ring slots stay registers
+    constexpr int s = decltype(s_c)::value;
+    {
+      const int qy = h0 - 2 + s, cy = min(max(qy, 0), H - 1);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const long qm = img + (long)cy * W + ixs[k];
+        g[s % 5][k] = *(const uint4*)(dy + qm * dy_ld + c);
+        pi[s % 5][k] = *(const uint2*)(idx + qm * C + c);
+      }
+    }
+    if (s >= 4) {
+      const int o = s - 4, h = h0 + o;
+      if (h < H) {
+        const long m = img + (long)h * W + w;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        if (accumulate) vload<T, VEC>(dx + m * dx_ld + c, acc);
+        // every window q = p + (oy, ox) that contains p; p sits at window position (2-oy, 2-ox) of q
+#pragma unroll
+        for (int oy = -2; oy <= 2; ++oy) {
+          const bool yok = (unsigned)(h + oy) < (unsigned)H;
+          const int slot = (o + oy + 2) % 5;
+#pragma unroll
+          for (int ox = -2; ox <= 2; ++ox) {
+            const bool ok = yok && cok[ox + 2];
+            const unsigned pos = (unsigned)((2 - oy) * 5 + (2 - ox));
+            typedef T vt __attribute__((ext_vector_type(VEC)));
+            const vt gv = __builtin_bit_cast(vt, g[slot][ox + 2]);
+            const uint2 pk = pi[slot][ox + 2];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const unsigned pb = ((i < 4 ? pk.x : pk.y) >> (8 * (i & 3))) & 255u;
+              if (ok && pb == pos) acc[i] += ElemTraits<T>::to_f(gv[i]);
+            }
+          }
+        }
+        vstore<T, VEC>(dx + m * dx_ld + c, acc);
+      }
+    }
+  });
+}
+
 extern "C" int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, int32_t x_ld,
                                  void* y, int32_t y_ld, uint8_t* idx, void* stream) {
   SY11_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && x && y && x_ld >= C && y_ld >= C, "maxpool5_fwd: bad argument");
@@ -821,6 +986,18 @@ extern "C" int sy11_maxpool5_fwd(int32_t dtype, int32_t B, int32_t H, int32_t W,
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
   dim3 grid(row_grid((long)B * H * W, g.rows_pb), g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
+  static int sep_env = -1;
+  if (sep_env < 0) { const char* e = getenv("SY11_MAXPOOL_SEP"); sep_env = e ? atoi(e) : 1; }
+  if (sep_env && v && esz == 2) {                      // separable row / column maxima, 5 rows of one column per thread
+    constexpr int RR = 5;
+    const int bands = (H + RR - 1) / RR, cpv8 = C / 8;
+    const long total = (long)B * bands * W * cpv8;
+    dim3 gs((unsigned)((total + 255) / 256));
+    if (dtype == SY11_F16) hipLaunchKernelGGL((maxpool5_fwd_sep_kernel<_Float16, RR>), gs, block, 0, st, B, H, W, C, (const _Float16*)x, x_ld, (_Float16*)y, y_ld, idx, cpv8, bands, total);
+    else hipLaunchKernelGGL((maxpool5_fwd_sep_kernel<__bf16, RR>), gs, block, 0, st, B, H, W, C, (const __bf16*)x, x_ld, (__bf16*)y, y_ld, idx, cpv8, bands, total);
+    SY11_LAUNCH_CHECK("maxpool5_fwd");
+    return SY11_OK;
+  }
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
     if (v) hipLaunchKernelGGL((maxpool5_fwd_kernel<T, VE>), grid, block, 0, st, B, H, W, C, (const T*)x, x_ld, (T*)y, y_ld, idx, g.cpv, g.rows_pb);
@@ -838,6 +1015,18 @@ extern "C" int sy11_maxpool5_bwd(int32_t dtype, int32_t B, int32_t H, int32_t W,
   const RowGeom g = row_geom(C, v ? 16 / esz : 1);
   dim3 grid(row_grid((long)B * H * W, g.rows_pb), g.cblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
+  static int walk_env = -1;
+  if (walk_env < 0) { const char* e = getenv("SY11_MAXPOOL_SEP"); walk_env = e ? atoi(e) : 1; }
+  if (walk_env && v && esz == 2) {                     // five rows of one column per thread, each row of (dy, argmax) pairs loaded once
+    constexpr int RR = 5;
+    const int bands = (H + RR - 1) / RR, cpv8 = C / 8;
+    const long total = (long)B * bands * W * cpv8;
+    dim3 gs((unsigned)((total + 255) / 256));
+    if (dtype == SY11_F16) hipLaunchKernelGGL((maxpool5_bwd_walk_kernel<_Float16, RR>), gs, block, 0, st, B, H, W, C, (const _Float16*)dy, dy_ld, idx, (_Float16*)dx, dx_ld, accumulate, cpv8, bands, total);
+    else hipLaunchKernelGGL((maxpool5_bwd_walk_kernel<__bf16, RR>), gs, block, 0, st, B, H, W, C, (const __bf16*)dy, dy_ld, idx, (__bf16*)dx, dx_ld, accumulate, cpv8, bands, total);
+    SY11_LAUNCH_CHECK("maxpool5_bwd");
+    return SY11_OK;
+  }
   SY11_DISPATCH_DTYPE(dtype, T, {
     constexpr int VE = 16 / (int)sizeof(T);
     if (v) hipLaunchKernelGGL((maxpool5_bwd_kernel<T, VE>), grid, block, 0, st, B, H, W, C, (const T*)dy, dy_ld, idx, (T*)dx, dx_ld, accumulate, g.cpv, g.rows_pb);

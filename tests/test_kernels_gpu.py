@@ -526,6 +526,50 @@ def test_copy_upsample_maxpool(dtype):
     close(to_nchw(dxp), xr.grad, dtype, "maxpool bwd (tie routing)", mult=4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,Cn,H,W", [(3, 64, 20, 20), (2, 24, 7, 3), (1, 8, 1, 1), (2, 16, 5, 23), (1, 40, 11, 4), (2, 8, 2, 9)])
+def test_maxpool5_values_and_argmax_against_aten(B, Cn, H, W, dtype):
+    """5 x 5 stride-1 max-pool: values bit-exact and the stored window position = ATen's argmax (first maximum in row-major window
+    order) on inputs full of ties, zeros of both signs and negative plateaus — the separable 16-bit kernel and the 25-way f32 one."""
+    o = ops()
+    xt = (rnd(B, Cn, H, W, seed=71) * 2).round() / 2                  # plateaus
+    xt[:, : Cn // 2] = -xt[:, : Cn // 2].abs()                         # all-negative channels (a zero pad would win there)
+    xt[0, -1] = 0.0
+    xt[0, -1, ::2] = -0.0
+    xv = nhwc(xt, dtype)
+    yv = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    idx = torch.empty(B, H, W, Cn, dtype=torch.uint8, device=DEV)
+    o.maxpool5_fwd(xv, yv, idx)
+    ref, ref_i = F.max_pool2d(q(xt, dtype), 5, 1, 2, return_indices=True)
+    assert torch.equal(to_nchw(yv).float(), ref)
+    pos = idx.permute(0, 3, 1, 2).cpu().long()                          # (B, C, H, W) window positions 0..24
+    hh = torch.arange(H).view(1, 1, H, 1) + pos // 5 - 2
+    ww = torch.arange(W).view(1, 1, 1, W) + pos % 5 - 2
+    assert bool(((hh >= 0) & (hh < H) & (ww >= 0) & (ww < W)).all())
+    got = hh * W + ww
+    # ATen keeps the FIRST maximum; +0 / -0 compare equal there: compare indices where the maximum is unique in value AND sign-
+    # insensitive, i.e. everywhere except windows whose maximum is a zero of mixed sign
+    flat = q(xt, dtype).reshape(B, Cn, H * W)
+    same_val = torch.gather(flat, 2, got.reshape(B, Cn, -1)) == torch.gather(flat, 2, ref_i.reshape(B, Cn, -1))
+    assert bool(same_val.all())
+    nonzero_max = (ref != 0)
+    assert torch.equal(got[nonzero_max], ref_i[nonzero_max])
+    # backward: routes dy to the argmax, plain and accumulating, against autograd of the same pooling
+    xr = q(xt, dtype).requires_grad_(True)
+    gp = rnd(B, Cn, H, W, seed=72)
+    F.max_pool2d(xr, 5, 1, 2).backward(q(gp, dtype))
+    dxv = torch.empty(B, H, W, Cn, dtype=dtype, device=DEV)
+    o.maxpool5_bwd(nhwc(gp, dtype), idx, dxv)
+    routed = torch.zeros(B, Cn, H * W).scatter_add_(2, got.reshape(B, Cn, -1), q(gp, dtype).reshape(B, Cn, -1)).reshape(B, Cn, H, W)
+    close(to_nchw(dxv), routed, dtype, "maxpool bwd vs its own argmax", mult=4)
+    ok = nonzero_max.reshape(B, Cn, -1).all(2)                          # channels without signed-zero ties: ATen routes the same way
+    close(to_nchw(dxv)[ok], xr.grad[ok], dtype, "maxpool bwd vs autograd", mult=4)
+    old = nhwc(rnd(B, Cn, H, W, seed=73), dtype)
+    acc = old.clone()
+    o.maxpool5_bwd(nhwc(gp, dtype), idx, acc, accumulate=True)
+    close(to_nchw(acc), to_nchw(old) + routed, dtype, "maxpool bwd accumulate", mult=6)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("B,H,W,heads", [(2, 6, 5, 2), (1, 20, 20, 4), (2, 3, 3, 1), (3, 10, 10, 2), (2, 8, 4, 1), (1, 40, 40, 2)])
 def test_attention_fwd_bwd(B, H, W, heads, dtype):
