@@ -166,7 +166,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   // what the 32 KB L1 keeps — so every tap goes to L2 again.  Channel-major (the T taps of one slab back to back) makes the
   // next stage read the rows the previous one just fetched, shifted by one pixel: most of them are still in L1.
   const bool chan_major = a.chan_major && a.T > 1 && a.C % BK == 0;
-  const int bpol = __builtin_amdgcn_readfirstlane(a.bpol);
   const bool b_issue = (BN >= RPP) || (wave_u * RPI < BN);         // BN < rows-per-pass: only waves covering real rows issue
   __syncthreads();  // tap tables visible
   {
@@ -193,9 +192,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         const unsigned off = (kvalid && b_off[i] >= 0) ? (unsigned)(b_off[i] + wo) : OOB;
-        if (bpol == 1) lds_dma16_sc1(sb + i * (RPP * KB), off, wr_);
-        else if (bpol == 2) lds_dma16_nt(sb + i * (RPP * KB), off, wr_);
-        else lds_dma16(sb + i * (RPP * KB), off, wr_);
+        // (r02 tried sc1 / nt cache policies for the filter rows behind a run-time switch: no effect — and the switch put a branch
+        // chain around every filter copy of every stage; r03: one plain copy)
+        lds_dma16(sb + i * (RPP * KB), off, wr_);
       }
     }
     if (chan_major) {                             // all taps of one channel slab back to back (see chan_major above)
