@@ -1,0 +1,74 @@
+"""Hunt the rare 16-bit event: a trained state for which two f16 device steps in atomic mode (same state, same batch, only the
+order of f32 atomics differs) give gradients 1e-2 or more apart.  When found: the state is saved, and the gradient arriving at
+every module's output is compared between a usual and the unusual run, in backward order, to see where the difference enters.
+    python tools/f16_event_probe.py [states=12] [runs=12]"""
+import os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "spectrogram-yolov11_amd"))
+os.environ["SY11_DETERMINISTIC"] = "0"
+from types import SimpleNamespace
+import torch
+from sy11 import _lib
+from sy11.nn.tasks import DetectionModel
+from tests._f16_parity import pretrained_state, pinned_device_step, GAINS, DEV
+
+states = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+runs = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+cfg, nc, nb, sz = "yolo11n.yaml", 80, 16, 256
+g = torch.Generator().manual_seed(3)
+img = torch.rand(nb, 3, sz, sz, generator=g)
+n = 2 * nb
+batch = {"img": img, "batch_idx": torch.arange(nb).repeat_interleave(2).float(), "cls": torch.randint(0, nc, (n, 1), generator=g).float(),
+         "bboxes": torch.cat((0.3 + 0.4 * torch.rand(n, 2, generator=g), 0.15 + 0.4 * torch.rand(n, 2, generator=g)), 1)}
+
+
+def dev(sd, pin=None, scale=64.0):
+    m = DetectionModel(cfg, ch=3, nc=nc, verbose=False)
+    m.args = SimpleNamespace(box=GAINS[0], cls=GAINS[1], dfl=GAINS[2])
+    m.load_state_dict(sd)
+    m._sy11_dtype = torch.float16
+    m = m.to(DEV).train()
+    got, order = {}, []
+
+    def fwd_hook(name):
+        def f(mod, inp, out):
+            if torch.is_tensor(out) and out.requires_grad:
+                order.append(name)
+                out.register_hook(lambda gr, name=name: got.__setitem__(name, gr.detach().float().cpu()))
+        return f
+    for name, mod in m.named_modules():
+        if name:
+            mod.register_forward_hook(fwd_hook(name))
+    loss, grads, maps, assign, _ = pinned_device_step(m, batch, nc, scale, pin)
+    return grads, got, order, assign
+
+
+def dist(a, b, keys):
+    fa, fb = torch.cat([a[k].flatten() for k in keys]), torch.cat([b[k].flatten() for k in keys])
+    return (fa - fb).norm().item() / fb.norm().item()
+
+
+for s in range(states):
+    _lib.set_option("deterministic", 0)
+    sd = pretrained_state(cfg, nc, nb, sz, 200)
+    first = dev(sd)
+    B, A = first[3].shape
+    pin = (first[3].clone(), None)
+    res = [first] + [dev(sd) for _ in range(runs - 1)]
+    keys = sorted(first[0])
+    same = [torch.equal(r[3], first[3]) for r in res]
+    d = [dist(r[0], first[0], keys) for r in res]
+    print(f"state {s}: whole-gradient distance of runs 1..{runs - 1} from run 0: " + " ".join(f"{x:.1e}" for x in d[1:]) + f"   assignment equal: {all(same)}", flush=True)
+    far = [i for i, x in enumerate(d) if x > 1e-2]
+    if far and len(far) < runs - 1:
+        i = far[0]
+        j = next(k for k in range(1, runs) if k not in far)
+        torch.save(sd, ROOT / "gpurun_out" / "f16_event_state.pt")
+        print(f"  run {i} is unusual; module-output gradients, run {i} vs run 0 (and usual run {j} vs run 0), in backward order:")
+        for name in reversed(first[2]):
+            if name in res[i][1] and name in first[1] and name in res[j][1]:
+                a, b, c = res[i][1][name], first[1][name], res[j][1][name]
+                nb_ = b.norm().item() + 1e-30
+                print(f"    {name:28s} {(a - b).norm().item() / nb_:.3e}   ({(c - b).norm().item() / nb_:.3e})   norm {nb_:.3e}  max|g| {b.abs().max().item():.3e}")
+        break
