@@ -265,7 +265,22 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float
       label = max((int)gt[0], 0);
       tx1 = gt[1] / st; ty1 = gt[2] / st; tx2 = gt[3] / st; ty2 = gt[4] / st;   // target_bboxes /= stride (loss.py:266)
     }
-    // ---- classification: BCE with logits against onehot(label) * w
+    // ---- classification: BCE with logits against onehot(label) * w.  Four classes per lane and access when the row allows it:
+    // a group of 16 lanes then moves 256 contiguous bytes per instruction instead of 64 (the rows are 4 * (64 + nc) bytes apart)
+    if ((a.nc & 3) == 0 && (((uintptr_t)row | (uintptr_t)drow) & 15) == 0) {
+      for (int c4 = j; c4 < (a.nc >> 2); c4 += 16) {
+        const f32x4 x4 = *(const f32x4*)(row + 4 * REG + 4 * c4);
+        f32x4 d4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x = x4[q];
+          const float t = (4 * c4 + q == label) ? w : 0.f;
+          if (!BWD) l_cls += fmaxf(x, 0.f) - x * t + __logf(1.f + __expf(-fabsf(x)));
+          else d4[q] = (__builtin_amdgcn_rcpf(1.f + __expf(-x)) - t) * a.gain_cls * up;
+        }
+        if (BWD) *(f32x4*)(drow + 4 * REG + 4 * c4) = d4;
+      }
+    } else
     for (int c = j; c < a.nc; c += 16) {
       const float x = row[4 * REG + c];
       const float t = (c == label) ? w : 0.f;
