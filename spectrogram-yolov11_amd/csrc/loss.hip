@@ -267,8 +267,10 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float
     }
     // ---- classification: BCE with logits against onehot(label) * w.  Four classes per lane and access when the row allows it:
     // a group of 16 lanes then moves 256 contiguous bytes per instruction instead of 64 (the rows are 4 * (64 + nc) bytes apart)
+    int c_tail = 0;                                              // classes below c_tail go four per lane, the rest one per lane
     if ((a.nc & 3) == 0 && (((uintptr_t)row | (uintptr_t)drow) & 15) == 0) {
-      for (int c4 = j; c4 < (a.nc >> 2); c4 += 16) {
+      c_tail = a.nc & ~63;                                       // whole rounds of 16 lanes x 4 classes only: every lane stays busy
+      for (int c4 = j; c4 < (c_tail >> 2); c4 += 16) {
         const f32x4 x4 = *(const f32x4*)(row + 4 * REG + 4 * c4);
         f32x4 d4;
 #pragma unroll
@@ -280,8 +282,8 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const LossArgs a, float
         }
         if (BWD) *(f32x4*)(drow + 4 * REG + 4 * c4) = d4;
       }
-    } else
-    for (int c = j; c < a.nc; c += 16) {
+    }
+    for (int c = c_tail + j; c < a.nc; c += 16) {
       const float x = row[4 * REG + c];
       const float t = (c == label) ? w : 0.f;
       if (!BWD) {
