@@ -446,6 +446,12 @@ def main():
         # the kernel(s) of the call, not the host's launch latency (r01: eager event timing read 9.8 ms for a family that takes
         # 8.8 ms under graph replay)
         from sy11.engine import module_post_backward
+        import sy11.engine as _engine
+        # ... and ONE stream: in the headline run the filter gradients are launched on a second stream and overlap the main chain
+        # (every kernel of both streams then runs slower than alone, the step faster).  A kernel's roofline position is the
+        # kernel's own: this instrumented step launches everything on the launch stream, as `profiles/<round>/z_serial_*`
+        # (the same command with SY11_WGRAD_STREAM=0) does; `z_final_*` is the headline command as it runs.
+        _side_was, _engine._SIDE_WGRAD = _engine._SIDE_WGRAD, False
         tr.model.__dict__.pop("_sy11_graph_cfg", None)          # per-launch events need individually launched kernels
         store = tr.model.__dict__.get("_sy11_grads")
         hook = module_post_backward.pop(id(store), None) if (store is not None and world > 1) else None   # the collective happened above
@@ -462,6 +468,7 @@ def main():
         step()
         torch.cuda.synchronize()
         prof, _lib.PROFILE = _lib.PROFILE, None
+        _engine._SIDE_WGRAD = _side_was
         pair_ms = sorted(c0.elapsed_time(c1) for c0, c1 in empty)[len(empty) // 2]
         if hook is not None:
             module_post_backward[id(store)] = hook
@@ -507,14 +514,16 @@ def main():
                            "source": f"profiles/{PROFILE_DIR.name}/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections)",
                            "commit": json.loads(tj.read_text()).get("commit"), "commands": json.loads(tj.read_text()).get("commands")}
         dominant = None
-        kcsv = PROFILE_DIR / "z_final_per_step_kernels.csv"
+        kcsv = PROFILE_DIR / "z_serial_per_step_kernels.csv"
+        if not kcsv.exists():
+            kcsv = PROFILE_DIR / "z_final_per_step_kernels.csv"
         if kcsv.exists():                                        # hottest kernel SYMBOL of the family in the committed graph-replay trace
             import csv
             rows = [r for r in csv.DictReader(open(kcsv)) if r["family"] == name]
             if rows:
                 top = max(rows, key=lambda r: float(r["ms_per_step"]))
                 dominant = {"symbol": top["kernel"], "launches_per_step": float(top["launches_per_step"]), "ms_per_step": float(top["ms_per_step"]),
-                            "avg_us_per_launch": float(top["avg_us_per_launch"]), "source": f"profiles/{PROFILE_DIR.name}/z_final_per_step_kernels.csv (rocprofv3 --kernel-trace --stats of this command)"}
+                            "avg_us_per_launch": float(top["avg_us_per_launch"]), "source": f"profiles/{PROFILE_DIR.name}/{kcsv.name} (rocprofv3 --kernel-trace --stats of this command, kernels one at a time: SY11_WGRAD_STREAM=0)"}
         roof = {"kernel": name, "kernel_symbols": list(FAMILIES.get(name, {}).get("symbols", ())), "dominant_symbol": dominant,
                 "bound": "hbm" if hbm_bound else "mfma",
                 "achieved": round(ach_gb, 1) if hbm_bound else round(ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
@@ -531,7 +540,8 @@ def main():
                             for k, v in f["by_call"].items()},
                 "families_ms": {k: round(v["ms"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
                 "timing": "HIP events around each C-ABI call of one eager step issued behind a 60 ms head-start delay on the launch stream, "
-                          f"minus half the span of an empty event pair ({pair_ms * 1e3:.1f} us)"}
+                          f"minus half the span of an empty event pair ({pair_ms * 1e3:.1f} us); every kernel on ONE stream for this "
+                          "step (the headline run overlaps the filter gradients on a second stream: each kernel slower, the step faster)"}
 
     peaks = measured_peaks(dev) if (rank == 0 and not a.no_roofline) else None
 

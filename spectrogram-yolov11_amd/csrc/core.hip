@@ -76,9 +76,15 @@ float* sy11_det_workspace(hipStream_t st, size_t bytes) {
   if (cs != hipStreamCaptureStatusNone) {
     // cannot allocate inside a capture.  The engine captures on a fresh stream after eager warm-up steps of the same shapes on the
     // launch stream, and replays the graph ON that launch stream, in order with its eager kernels: the warm-up's buffer is free
-    // whenever a node of this graph runs.  (Ordered mode therefore excludes the opt-in side / branch streams of the engine.)
-    for (auto& kv : g_det_ws)
-      if (kv.second.bytes >= bytes) return (float*)kv.second.p;
+    // whenever a node of this graph runs.  A stream that is itself part of a capture right now (the engine's filter-gradient
+    // stream: the same stream object in the warm-up steps and in the capture, so it found its own buffer above) keeps its buffer
+    // to itself — two branches of one graph run concurrently and must not fold through the same rows.
+    for (auto& kv : g_det_ws) {
+      if (kv.second.bytes < bytes || kv.first == st) continue;
+      hipStreamCaptureStatus other = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(kv.first, &other) != hipSuccess) { (void)hipGetLastError(); continue; }
+      if (other == hipStreamCaptureStatusNone) return (float*)kv.second.p;
+    }
     return nullptr;                                                    // nothing large enough: the caller reports an error
   }
   size_t want = w.bytes ? w.bytes * 2 : (size_t)64 << 20;

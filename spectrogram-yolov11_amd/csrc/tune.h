@@ -69,6 +69,10 @@ int pick(const int* cands, int ncand, F&& run, hipStream_t st, const char* what,
   std::lock_guard<std::mutex> guard(mu);
   static hipEvent_t e0 = nullptr, e1 = nullptr;
   if (!e0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) { (void)hipGetLastError(); return -1; }
+  // candidates are timed with the rest of the GPU idle: the caller may be one of several streams (the engine launches filter
+  // gradients on a second one), and kernels still draining elsewhere would be timed along with the first candidates.  Never
+  // reached while `st` is being captured (the callers check), and measuring is a first-call event per problem key.
+  (void)hipDeviceSynchronize();
   int best = -1;
   float best_ms = 0.f;
   for (int i = 0; i < ncand; ++i) {

@@ -94,11 +94,19 @@ class Act:
         self._ready = True
 
 
-# Off by default: measured on MI355X (r01, 3 A/B pairs) the fork/join dependency costs ~10 us per layer inside the captured
-# graph and the overlap does not pay it back (26.55 ms vs 27.05 ms per step) — the kernels already fill every CU.
-_SIDE_WGRAD = os.environ.get("SY11_WGRAD_STREAM", "0") != "0"
-# > 1: batch that many filter-gradient launches per fork (one cross-stream edge per batch instead of one per layer)
-_SIDE_BATCH = max(int(os.environ.get("SY11_WGRAD_STREAM", "0") or 0), 1)
+# Filter gradients on a second stream, SY11_WGRAD_STREAM of them per fork (0 = everything on one stream).  Inside the captured
+# graph a cross-stream edge costs ~10 us, so one fork per layer LOSES (r01: 26.55 -> 27.05 ms; r03: 19.93 -> 20.65) — but the
+# replayed graph otherwise runs strictly one kernel at a time (rocprofv3 trace of the r03 build: 643 kernels, 0.000 ms with two
+# kernels in flight), and the filter gradients (MFMA / LDS bound, 2.6 TB/s) pair well with the BatchNorm passes (HBM bound) of
+# the layers below them.  Batched, the fork count drops to three per step: same-box sweep 0 / 16 / 24 / 32 / 48 / 64 / 100 per
+# fork = 19.73 / 19.48 / 19.36 / 19.26 / 19.45 / 19.47 / 19.76 ms (32 again 19.26, 0 again 19.61; second box 19.94 -> 19.55).
+_SIDE_WGRAD = os.environ.get("SY11_WGRAD_STREAM", "32") != "0"
+# how many filter-gradient launches share one fork (one cross-stream edge per batch instead of one per layer)
+_SIDE_BATCH = max(int(os.environ.get("SY11_WGRAD_STREAM", "32") or 0), 1)
+# (Measured and dropped: forking by WORK instead of count — a batch per 0.5 / 1 / 2 / 4 / 8 x 1e8 gradient elements, so that the
+# few large layers at the end of the backward pass overlap too: 20.23 / 19.76 / 19.89 / 19.50 / 19.61 ms against 19.52-19.56 by
+# count.  The large maps' filter gradients are HBM-bound like the BatchNorm passes they would run beside; the pairing pays on the
+# small maps, where neither kernel fills the chip.)
 _SIDE_STREAMS = {}
 
 

@@ -99,6 +99,31 @@ def test_trainer_steps_with_graph_replay_are_bit_identical(deterministic, amp):
     assert torch.isfinite(a[0]).all()
 
 
+def test_filter_gradient_stream_does_not_change_an_ordered_run(deterministic, monkeypatch):
+    """The engine launches filter gradients on a second stream, a batch per fork (sy11/engine/__init__.py, SY11_WGRAD_STREAM); in the
+    captured graph they are branches that run beside the main chain.  Ordered sums must not notice: 5 trainer steps (eager + capture
+    + replays, f16) with no second stream, with 3 launches per fork and with 32 give bit-identical weights, EMA and losses.  (r03:
+    both streams of a capture were handed the same fold workspace — this test is the regression.)"""
+    import sy11.engine as E
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+
+    def run(batch_per_fork):
+        monkeypatch.setattr(E, "_SIDE_WGRAD", batch_per_fork > 0)
+        monkeypatch.setattr(E, "_SIDE_BATCH", max(batch_per_fork, 1))
+        m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
+        m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
+        tr = DetectionTrainer(m, batch_size=8, device=DEV, overrides={"amp": True, "nbs": 8, "warmup_epochs": 0, "deterministic": True}, graphs=True)
+        losses = [tr.train_step(dict(_batch(8, 128, 80, seed=10 + i)))[0].clone() for i in range(5)]
+        return torch.stack(losses), tr.flat.flat.clone(), tr.ema.ema_state.flat.clone()
+    ref = run(0)
+    for n in (3, 32):
+        got = run(n)
+        for x, y, what in zip(got, ref, ("losses", "weights", "EMA")):
+            assert _same(x, y), f"{n} filter gradients per fork, {what}: {int((x != y).sum())} of {x.numel()} values differ from the one-stream run"
+    assert torch.isfinite(ref[0]).all()
+
+
 def test_full_size_step_is_bit_identical(deterministic):
     """The bench's shape: yolo11s, 64 x 3 x 640 x 640, f16."""
     batch = _batch(64, 640, 80, seed=5)
