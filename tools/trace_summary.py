@@ -23,9 +23,20 @@ mode = max(set(sizes), key=sizes.count)
 good = [i for i in range(len(marks) - 1) if sizes[i] == mode][-nsteps:]
 sym = defaultdict(lambda: [0, 0])
 span = busy = 0
+union = two = 0                       # time with >= 1 / >= 2 kernels in flight (the engine's second stream: filter gradients)
+queues = set()
 for i in good:
     step = rows[marks[i]:marks[i + 1]]
     span += int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"])
+    ev = sorted([(int(r["Start_Timestamp"]), 1) for r in step] + [(int(r["End_Timestamp"]), -1) for r in step])
+    live, last = 0, None
+    for t, d in ev:
+        if last is not None:
+            union += (t - last) if live >= 1 else 0
+            two += (t - last) if live >= 2 else 0
+        live += d
+        last = t
+    queues |= {r.get("Queue_Id") for r in step}
     for r in step:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         busy += d
@@ -61,6 +72,9 @@ with open(dst + "_per_step_families.csv", "w", newline="") as f:
     for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         w.writerow([k, round(c / n, 2), round(t / n / 1e6, 4), round(t / c / 1e3, 2), round(t / busy, 4)])
     w.writerow(["(step span)", round(mode, 0), round(span / n / 1e6, 4), "", round(busy / span, 4)])
-print(f"{n} replayed steps of {mode} kernels: span {span / n / 1e6:.3f} ms, busy {busy / n / 1e6:.3f} ms")
+    w.writerow(["(>= 1 kernel in flight)", "", round(union / n / 1e6, 4), "", round(union / span, 4)])
+    w.writerow(["(>= 2 kernels in flight)", len(queues), round(two / n / 1e6, 4), "", round(two / span, 4)])
+print(f"{n} replayed steps of {mode} kernels: span {span / n / 1e6:.3f} ms, sum of kernel durations {busy / n / 1e6:.3f} ms, "
+      f">= 1 kernel in flight {union / n / 1e6:.3f} ms, >= 2 in flight {two / n / 1e6:.3f} ms, {len(queues)} queue(s)")
 for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:28s} {c / n:7.1f} launches  {t / n / 1e6:8.3f} ms/step")
