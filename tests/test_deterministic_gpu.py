@@ -124,6 +124,32 @@ def test_filter_gradient_stream_does_not_change_an_ordered_run(deterministic, mo
     assert torch.isfinite(ref[0]).all()
 
 
+@pytest.mark.parametrize("mode", ["ordered", "atomic"])
+def test_filter_gradient_stream_in_eager_steps(deterministic, monkeypatch, mode):
+    """The same in EAGER steps (no graph: the launches go to a real second stream while the allocator may hand out freed blocks):
+    one f32 step of yolo11n with 0 / 1 / 5 filter gradients per fork — bit-identical in ordered mode, within the run-to-run spread of
+    the f32 atomics (1e-4 of the gradient norm) in the default mode."""
+    import sy11.engine as E
+    from sy11 import _lib
+    layers = R.resolve_graph("n", nc=80)
+    batch = _batch(8, 160, 80, seed=6)
+    if mode == "atomic":
+        _lib.set_option("deterministic", 0)
+
+    def run(n):
+        monkeypatch.setattr(E, "_SIDE_WGRAD", n > 0)
+        monkeypatch.setattr(E, "_SIDE_BATCH", max(n, 1))
+        return _one_step("yolo11n.yaml", layers, 80, torch.float32, batch)
+    ref = run(0)
+    for n in (1, 5):
+        got = run(n)
+        if mode == "ordered":
+            assert _same(got[2], ref[2]) and _same(got[0], ref[0]), f"{n} per fork: {int((got[2] != ref[2]).sum())} gradient elements differ"
+        else:
+            # the bar of test_mode_does_not_change_the_result: two atomic-mode runs differ by the order of the f32 atomics alone
+            assert (got[2] - ref[2]).norm().item() <= 1e-4 * ref[2].norm().item(), (n, (got[2] - ref[2]).norm().item() / ref[2].norm().item())
+
+
 def test_full_size_step_is_bit_identical(deterministic):
     """The bench's shape: yolo11s, 64 x 3 x 640 x 640, f16."""
     batch = _batch(64, 640, 80, seed=5)
