@@ -452,6 +452,7 @@ def main():
         # kernel's own: this instrumented step launches everything on the launch stream, as `profiles/<round>/z_serial_*`
         # (the same command with SY11_WGRAD_STREAM=0) does; `z_final_*` is the headline command as it runs.
         _side_was, _engine._SIDE_WGRAD = _engine._SIDE_WGRAD, False
+        _hoist_was, _engine._HEAD_HOIST = _engine._HEAD_HOIST, False        # (the Detect levels' branch streams likewise)
         tr.model.__dict__.pop("_sy11_graph_cfg", None)          # per-launch events need individually launched kernels
         store = tr.model.__dict__.get("_sy11_grads")
         hook = module_post_backward.pop(id(store), None) if (store is not None and world > 1) else None   # the collective happened above
@@ -468,7 +469,7 @@ def main():
         step()
         torch.cuda.synchronize()
         prof, _lib.PROFILE = _lib.PROFILE, None
-        _engine._SIDE_WGRAD = _side_was
+        _engine._SIDE_WGRAD, _engine._HEAD_HOIST = _side_was, _hoist_was
         pair_ms = sorted(c0.elapsed_time(c1) for c0, c1 in empty)[len(empty) // 2]
         if hook is not None:
             module_post_backward[id(store)] = hook
@@ -523,7 +524,7 @@ def main():
             if rows:
                 top = max(rows, key=lambda r: float(r["ms_per_step"]))
                 dominant = {"symbol": top["kernel"], "launches_per_step": float(top["launches_per_step"]), "ms_per_step": float(top["ms_per_step"]),
-                            "avg_us_per_launch": float(top["avg_us_per_launch"]), "source": f"profiles/{PROFILE_DIR.name}/{kcsv.name} (rocprofv3 --kernel-trace --stats of this command, kernels one at a time: SY11_WGRAD_STREAM=0)"}
+                            "avg_us_per_launch": float(top["avg_us_per_launch"]), "source": f"profiles/{PROFILE_DIR.name}/{kcsv.name} (rocprofv3 --kernel-trace --stats of this command, kernels one at a time: SY11_WGRAD_STREAM=0 SY11_HEAD_HOIST=0)"}
         roof = {"kernel": name, "kernel_symbols": list(FAMILIES.get(name, {}).get("symbols", ())), "dominant_symbol": dominant,
                 "bound": "hbm" if hbm_bound else "mfma",
                 "achieved": round(ach_gb, 1) if hbm_bound else round(ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,

@@ -124,6 +124,15 @@ def _side_stream(device):
 # per step with the branches against 22.40 / 22.38 ms on one stream — as with the filter-gradient stream above, parallel branches
 # of a hipGraph cost more than the idle CUs they fill.  SY11_BRANCH_STREAMS=1 turns it on.
 _BRANCH_STREAMS_ON = os.environ.get("SY11_BRANCH_STREAMS", "0") != "0"
+# The Detect chains of a level launched as soon as that level's feature map exists (BaseModel._run), on the level's branch
+# stream: the stride-8 level's six 80x80 convolutions then run beside the 40x40 / 20x20 neck layers 17-22 that follow its input,
+# instead of after them (forward; in the backward pass a level's closures keep their place in the tape and run on the branch
+# stream between the main-stream closures around them).  Implies the branch streams.  Same-box A/B, two pairs: 19.61 / 19.71 ms
+# without, 19.52 / 19.43 with (-0.9 %).  OFF by default (SY11_HEAD_HOIST=1 turns it on): through graph replay an ordered-mode run
+# is bit-identical with and without it (tests/test_deterministic_gpu.py), but ONE EAGER f32 step in ordered mode came out
+# different from the un-hoisted step in 1.5 M of 2.6 M gradient elements — a reordered accumulation into the shared input gradient
+# of a level, or a race, not yet told apart.  Until it is, the engine keeps the head where the reference has it.
+_HEAD_HOIST = os.environ.get("SY11_HEAD_HOIST", "0") != "0"
 _BRANCH_STREAMS = {}
 
 
@@ -191,7 +200,8 @@ class Ctx:
         self.side = None
         self.side_refs: List = []
         self.use_side = _SIDE_WGRAD and device is not None and torch.device(device).type == "cuda"
-        self.use_branches = _BRANCH_STREAMS_ON and device is not None and torch.device(device).type == "cuda"
+        self.hoist_head = _HEAD_HOIST and device is not None and torch.device(device).type == "cuda"
+        self.use_branches = (_BRANCH_STREAMS_ON or self.hoist_head) and device is not None and torch.device(device).type == "cuda"
         self.open_branches = set()
         self.tape_branches: List = []     # (first tape index, end, branch) of the closures recorded inside a branch section
 

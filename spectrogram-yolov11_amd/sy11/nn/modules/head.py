@@ -84,17 +84,25 @@ class Detect(nn.Module):
                 h = m._run(ec, h)
         conv2d_bias_run(ec, seq[-1], h, out)
 
-    def _run(self, ec: Ctx, xs):
+    def _level(self, ec: Ctx, i: int, x: Act) -> Act:
+        """Both chains of level ``i`` (box: cv2[i], class: cv3[i]) into one (B, H, W, no) map."""
+        B, H, W, _ = x.shape
+        m = Act(ec.empty(B, H, W, self.no, dtype=torch.float32))      # logits stay f32 (loss / decode)
+        self._branch(ec, self.cv2[i], x, m.slice(0, 4 * self.reg_max))
+        self._branch(ec, self.cv3[i], x, m.slice(4 * self.reg_max, self.no))
+        return m
+
+    def _run(self, ec: Ctx, xs, pre=None):
+        """``pre``: {level: map} of levels BaseModel._run already launched on their branch streams (head hoisting)."""
         if self.end2end:
             raise ops._lib.Sy11Error("end2end (v10) heads are outside the hot path")
         maps = []
         for i in range(self.nl):                                # the levels are independent: one stream (graph branch) each
+            if pre and i in pre:
+                maps.append(pre[i])
+                continue
             with ec.branch(i):
-                B, H, W, _ = xs[i].shape
-                m = Act(ec.empty(B, H, W, self.no, dtype=torch.float32))      # logits stay f32 (loss / decode)
-                self._branch(ec, self.cv2[i], xs[i], m.slice(0, 4 * self.reg_max))
-                self._branch(ec, self.cv3[i], xs[i], m.slice(4 * self.reg_max, self.no))
-                maps.append(m)
+                maps.append(self._level(ec, i, xs[i]))
         ec.join_branches()
         if ec.training:
             return maps

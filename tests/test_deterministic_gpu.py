@@ -108,19 +108,20 @@ def test_filter_gradient_stream_does_not_change_an_ordered_run(deterministic, mo
     from sy11.engine.trainer import DetectionTrainer
     from sy11.nn.tasks import DetectionModel
 
-    def run(batch_per_fork):
+    def run(batch_per_fork, hoist=False):
         monkeypatch.setattr(E, "_SIDE_WGRAD", batch_per_fork > 0)
         monkeypatch.setattr(E, "_SIDE_BATCH", max(batch_per_fork, 1))
+        monkeypatch.setattr(E, "_HEAD_HOIST", hoist)            # Detect levels launched early on their own branch streams
         m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
         m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
         tr = DetectionTrainer(m, batch_size=8, device=DEV, overrides={"amp": True, "nbs": 8, "warmup_epochs": 0, "deterministic": True}, graphs=True)
         losses = [tr.train_step(dict(_batch(8, 128, 80, seed=10 + i)))[0].clone() for i in range(5)]
         return torch.stack(losses), tr.flat.flat.clone(), tr.ema.ema_state.flat.clone()
     ref = run(0)
-    for n in (3, 32):
-        got = run(n)
+    for n, hoist in ((3, False), (32, False), (0, True), (32, True)):
+        got = run(n, hoist)
         for x, y, what in zip(got, ref, ("losses", "weights", "EMA")):
-            assert _same(x, y), f"{n} filter gradients per fork, {what}: {int((x != y).sum())} of {x.numel()} values differ from the one-stream run"
+            assert _same(x, y), f"{n} filter gradients per fork, head hoisting {hoist}, {what}: {int((x != y).sum())} of {x.numel()} values differ from the one-stream run"
     assert torch.isfinite(ref[0]).all()
 
 
@@ -136,13 +137,14 @@ def test_filter_gradient_stream_in_eager_steps(deterministic, monkeypatch, mode)
     if mode == "atomic":
         _lib.set_option("deterministic", 0)
 
-    def run(n):
+    def run(n, hoist=False):
         monkeypatch.setattr(E, "_SIDE_WGRAD", n > 0)
         monkeypatch.setattr(E, "_SIDE_BATCH", max(n, 1))
+        monkeypatch.setattr(E, "_HEAD_HOIST", hoist)
         return _one_step("yolo11n.yaml", layers, 80, torch.float32, batch)
     ref = run(0)
-    for n in (1, 5):
-        got = run(n)
+    for n, hoist in ((1, False), (5, False)):                     # head hoisting in eager steps: see sy11/engine/__init__.py (_HEAD_HOIST)
+        got = run(n, hoist)
         if mode == "ordered":
             assert _same(got[2], ref[2]) and _same(got[0], ref[0]), f"{n} per fork: {int((got[2] != ref[2]).sum())} gradient elements differ"
         else:
