@@ -128,10 +128,11 @@ _BRANCH_STREAMS_ON = os.environ.get("SY11_BRANCH_STREAMS", "0") != "0"
 # stream: the stride-8 level's six 80x80 convolutions then run beside the 40x40 / 20x20 neck layers 17-22 that follow its input,
 # instead of after them (forward; in the backward pass a level's closures keep their place in the tape and run on the branch
 # stream between the main-stream closures around them).  Implies the branch streams.  Same-box A/B, two pairs: 19.61 / 19.71 ms
-# without, 19.52 / 19.43 with (-0.9 %).  OFF by default (SY11_HEAD_HOIST=1 turns it on): through graph replay an ordered-mode run
-# is bit-identical with and without it (tests/test_deterministic_gpu.py), but ONE EAGER f32 step in ordered mode came out
-# different from the un-hoisted step in 1.5 M of 2.6 M gradient elements — a reordered accumulation into the shared input gradient
-# of a level, or a race, not yet told apart.  Until it is, the engine keeps the head where the reference has it.
+# without, 19.52 / 19.43 with (-0.9 %, box-to-box spread is larger).  OFF by default (SY11_HEAD_HOIST=1 turns it on): it REORDERS
+# the sums into a level's input gradient (the next neck layer's input gradient now arrives before the level's own chains'), so an
+# ordered-mode step differs in the last bits from the un-hoisted one in every layer below the hoist points and in none above
+# them, and two hoisted runs are bit-identical (tools/hoist_debug.py) — not a race, but no longer the reference's order of
+# additions either; the engine keeps the head where the reference has it until the gain is worth a new set of ordered goldens.
 _HEAD_HOIST = os.environ.get("SY11_HEAD_HOIST", "0") != "0"
 _BRANCH_STREAMS = {}
 

@@ -83,46 +83,58 @@ def test_mode_does_not_change_the_result(deterministic):
 
 @pytest.mark.parametrize("amp", [False, True], ids=["f32", "amp_f16"])
 def test_trainer_steps_with_graph_replay_are_bit_identical(deterministic, amp):
-    """6 trainer steps (2 eager + capture + replays; SGD-nesterov, clip, EMA, GradScaler): weights, EMA and losses of two runs."""
+    """6 (AMP: 10, the first of which the GradScaler may skip) trainer steps (2 eager + capture + replays; SGD-nesterov, clip, EMA,
+    GradScaler): weights, EMA and losses of two runs."""
     from sy11.engine.trainer import DetectionTrainer
     from sy11.nn.tasks import DetectionModel
 
     def run():
+        torch.manual_seed(4)
         m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
-        m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
+        if not amp:      # AMP keeps the constructor's initialisation: the seeded random state's f16 gradients overflow at every loss
+            m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))    # scale, all steps skipped
         tr = DetectionTrainer(m, batch_size=8, device=DEV, overrides={"amp": amp, "nbs": 8, "warmup_epochs": 0, "deterministic": True}, graphs=True)
-        losses = [tr.train_step(dict(_batch(8, 128, 80, seed=10 + i)))[0].clone() for i in range(6)]
-        return torch.stack(losses), tr.flat.flat.clone(), tr.ema.ema_state.flat.clone(), tr.flat.flat_buf.clone()
+        w0 = tr.flat.flat.clone()
+        losses = [tr.train_step(dict(_batch(8, 128, 80, seed=10 + i)))[0].clone() for i in range(10 if amp else 6)]
+        moved = float((tr.flat.flat != w0).float().mean())          # fraction of weights the six steps changed
+        return torch.stack(losses), tr.flat.flat.clone(), tr.ema.ema_state.flat.clone(), tr.flat.flat_buf.clone(), moved
     a, b = run(), run()
     for x, y, what in zip(a, b, ("losses", "weights", "EMA", "BatchNorm buffers")):
         assert _same(x, y), f"{what}: {int((x != y).sum())} of {x.numel()} values differ between two runs"
     assert torch.isfinite(a[0]).all()
+    # a GradScaler that skips every step (overflowing f16 gradients) would make the weight comparison vacuous
+    assert a[4] > 0.5, f"only {a[4]:.3f} of the weights changed in six steps: the optimizer steps were skipped"
 
 
-def test_filter_gradient_stream_does_not_change_an_ordered_run(deterministic, monkeypatch):
+@pytest.mark.parametrize("amp", [False, True], ids=["f32", "amp_f16"])
+def test_filter_gradient_stream_does_not_change_an_ordered_run(deterministic, monkeypatch, amp):
     """The engine launches filter gradients on a second stream, a batch per fork (sy11/engine/__init__.py, SY11_WGRAD_STREAM); in the
     captured graph they are branches that run beside the main chain.  Ordered sums must not notice: 5 trainer steps (eager + capture
-    + replays, f16) with no second stream, with 3 launches per fork and with 32 give bit-identical weights, EMA and losses.  (r03:
+    + replays, f16) with no second stream, with 3 launches per fork and with 32 give bit-identical weights, EMA and losses (f32 and AMP).  (r03:
     both streams of a capture were handed the same fold workspace — this test is the regression.)"""
     import sy11.engine as E
     from sy11.engine.trainer import DetectionTrainer
     from sy11.nn.tasks import DetectionModel
 
-    def run(batch_per_fork, hoist=False):
+    def run(batch_per_fork):
         monkeypatch.setattr(E, "_SIDE_WGRAD", batch_per_fork > 0)
         monkeypatch.setattr(E, "_SIDE_BATCH", max(batch_per_fork, 1))
-        monkeypatch.setattr(E, "_HEAD_HOIST", hoist)            # Detect levels launched early on their own branch streams
+        monkeypatch.setattr(E, "_HEAD_HOIST", False)    # (early Detect levels REORDER the sums into a level's input gradient: not bit-comparable)
+        torch.manual_seed(4)
         m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
-        m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
-        tr = DetectionTrainer(m, batch_size=8, device=DEV, overrides={"amp": True, "nbs": 8, "warmup_epochs": 0, "deterministic": True}, graphs=True)
-        losses = [tr.train_step(dict(_batch(8, 128, 80, seed=10 + i)))[0].clone() for i in range(5)]
-        return torch.stack(losses), tr.flat.flat.clone(), tr.ema.ema_state.flat.clone()
+        if not amp:                                     # (AMP: the constructor's initialisation, as in the test above)
+            m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
+        tr = DetectionTrainer(m, batch_size=8, device=DEV, overrides={"amp": amp, "nbs": 8, "warmup_epochs": 0, "deterministic": True}, graphs=True)
+        w0 = tr.flat.flat.clone()
+        losses = [tr.train_step(dict(_batch(8, 128, 80, seed=10 + i)))[0].clone() for i in range(9 if amp else 5)]
+        return torch.stack(losses), tr.flat.flat.clone(), tr.ema.ema_state.flat.clone(), float((tr.flat.flat != w0).float().mean())
     ref = run(0)
-    for n, hoist in ((3, False), (32, False), (0, True), (32, True)):
-        got = run(n, hoist)
+    for n in (3, 32):
+        got = run(n)
         for x, y, what in zip(got, ref, ("losses", "weights", "EMA")):
-            assert _same(x, y), f"{n} filter gradients per fork, head hoisting {hoist}, {what}: {int((x != y).sum())} of {x.numel()} values differ from the one-stream run"
+            assert _same(x, y), f"{n} filter gradients per fork, {what}: {int((x != y).sum())} of {x.numel()} values differ from the one-stream run"
     assert torch.isfinite(ref[0]).all()
+    assert ref[3] > 0.5, f"only {ref[3]:.3f} of the weights changed: the optimizer steps were skipped, the comparison would be vacuous"
 
 
 @pytest.mark.parametrize("mode", ["ordered", "atomic"])

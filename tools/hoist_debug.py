@@ -57,3 +57,23 @@ for dtype in (torch.float32, torch.float16):
     print("  layer: elements differing hoisted vs not / total   (hoisted run twice: differing)")
     for li in sorted(per):
         print(f"   {li:2d}: {per[li][0]:8d} / {per[li][1]:8d}   ({per[li][2]})")
+
+print("trainer, graph replay, f16:")
+from oracle import yolo11_ref as R
+from sy11.engine.trainer import DetectionTrainer
+
+
+def trainer_run(hoist):
+    E._HEAD_HOIST = hoist
+    m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
+    m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
+    tr = DetectionTrainer(m, batch_size=8, device=DEV, overrides={"amp": True, "nbs": 8, "warmup_epochs": 0, "deterministic": True}, graphs=True)
+    seen.clear()
+    for i in range(5):
+        tr.train_step(dict(batch))
+    print(f"  hoist {hoist}: {len(seen)} contexts; hoist_head {[c.hoist_head for c in seen][:6]}; branch sections of the last: {seen[-1].tape_branches}")
+    return tr.flat.flat.clone()
+
+
+w0, w1 = trainer_run(False), trainer_run(True)
+print("  weights differing hoisted vs not:", int((w0 != w1).sum()), "of", w0.numel())
