@@ -1,7 +1,7 @@
 """GPU: the data-parallel path with REAL kernels — two ranks share cuda:0 over the gloo backend (one-GPU box; RCCL needs one
 GPU per rank).  Each rank runs DetectionTrainer with hipGraph replay: the backward is captured as TWO graphs around the bucket
 mark (SY11_DDP_OVERLAP=1; the default is one graph and ONE all-reduce after it), the first bucket's all-reduce is issued between
-them, rank 0's tuner picks reach rank 1, and both ranks hold bit-identical weights after 6 steps although they saw different
+them, rank 0's tuner picks reach rank 1, and both ranks hold bit-identical weights after 8 steps (and the weights have moved) although they saw different
 batches.  The RCCL flavour of this test (one GPU per rank) is tests/test_ddp_nccl_gpu.py; it skips on a one-GPU box."""
 import os
 import sys
@@ -29,7 +29,8 @@ SCRIPT = textwrap.dedent("""
     tr = DetectionTrainer(m, batch_size=4, device=dev, overrides={{"amp": True, "nbs": 8, "warmup_epochs": 0}}, world_size=world, graphs=True)
     assert tr.accumulate == 1 and (_lib.get_option("tune") == (1 if rank == 0 else 0))
     losses = []
-    for i in range(6):
+    w0 = tr.flat.flat.clone()
+    for i in range(8):
         g = torch.Generator().manual_seed(100 * rank + i)
         b = {{"img": torch.rand(4, 3, 128, 128, generator=g).to(dev), "batch_idx": torch.tensor([0., 1., 2., 3.]).to(dev),
              "cls": torch.randint(0, 80, (4, 1), generator=g).float().to(dev), "bboxes": (0.3 + 0.3 * torch.rand(4, 4, generator=g)).to(dev)}}
@@ -42,6 +43,9 @@ SCRIPT = textwrap.dedent("""
     mine = tr.flat.flat.clone()
     theirs = mine.clone(); dist.broadcast(theirs, 0)
     assert torch.equal(mine, theirs), (mine - theirs).abs().max()
+    moved = float((mine != w0).float().mean())         # a GradScaler that skipped every step would make the comparison above vacuous
+    assert moved > 0.5, f"only {{moved:.3f}} of the weights changed in eight steps"
+
     picks = _lib.tune_export()
     box = [picks]; dist.broadcast_object_list(box, 0)
     assert sorted(picks[i:i + 16] for i in range(0, len(picks), 16)) == sorted(box[0][i:i + 16] for i in range(0, len(box[0]), 16)) and len(picks) > 0

@@ -1,7 +1,7 @@
 """GPU (needs >= 2 visible GPUs — skips on the one-GPU test box): the data-parallel path over RCCL, one process per GPU, as
 `bench.py --gpus N` and the trainer run it.  Both flavours of the gradient exchange: the default (ONE all-reduce of the flat
 gradient buffer after the backward graph) and SY11_DDP_OVERLAP=1 (two-bucket exchange: the first bucket is reduced on RCCL's
-stream beside the second backward graph).  After 6 steps on different batches the ranks must hold bit-identical weights, and the
+stream beside the second backward graph).  After 8 steps on different batches the ranks must hold bit-identical weights, and the
 overlapped flavour must reproduce the default one bit for bit (the same sums in the same order, only scheduled differently)."""
 import os
 import sys
@@ -26,7 +26,8 @@ torch.manual_seed(5 + rank)
 m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
 tr = DetectionTrainer(m, batch_size=8, device=dev, overrides={{"amp": True, "nbs": 8 * world, "warmup_epochs": 0}}, world_size=world, graphs=True)
 losses = []
-for i in range(6):
+w0 = tr.flat.flat.clone()
+for i in range(8):
     g = torch.Generator().manual_seed(100 * rank + i)
     b = {{"img": torch.rand(8, 3, 256, 256, generator=g).to(dev), "batch_idx": torch.arange(8.0).to(dev),
          "cls": torch.randint(0, 80, (8, 1), generator=g).float().to(dev), "bboxes": (0.3 + 0.3 * torch.rand(8, 4, generator=g)).to(dev)}}
@@ -37,6 +38,8 @@ assert (e.g_bwd2 is not None) == (os.environ.get("SY11_DDP_OVERLAP", "0") == "1"
 mine = tr.flat.flat.clone()
 theirs = mine.clone(); dist.broadcast(theirs, 0)
 assert torch.equal(mine, theirs), float((mine - theirs).abs().max())
+moved = float((mine != w0).float().mean())             # a GradScaler that skipped every step would make the comparison above vacuous
+assert moved > 0.5, f"only {{moved:.3f}} of the weights changed in eight steps"
 picks = _lib.tune_export()
 box = [picks]; dist.broadcast_object_list(box, 0)
 assert sorted(picks[i:i + 16] for i in range(0, len(picks), 16)) == sorted(box[0][i:i + 16] for i in range(0, len(box[0]), 16))
