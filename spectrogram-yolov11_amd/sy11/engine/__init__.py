@@ -106,7 +106,8 @@ _SIDE_BATCH = max(int(os.environ.get("SY11_WGRAD_STREAM", "32") or 0), 1)
 # (Measured and dropped: forking by WORK instead of count — a batch per 0.5 / 1 / 2 / 4 / 8 x 1e8 gradient elements, so that the
 # few large layers at the end of the backward pass overlap too: 20.23 / 19.76 / 19.89 / 19.50 / 19.61 ms against 19.52-19.56 by
 # count.  The large maps' filter gradients are HBM-bound like the BatchNorm passes they would run beside; the pairing pays on the
-# small maps, where neither kernel fills the chip.)
+# small maps, where neither kernel fills the chip.  An EARLIER first fork — 12 / 20 / 8 launches, then 32 / 40 / 36 — also loses:
+# 19.72 / 19.74 / 20.06 ms against 19.57-19.59.)
 _SIDE_STREAMS = {}
 
 
