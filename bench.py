@@ -4,7 +4,8 @@
 A "step" = one pass of the hot path over one synthetic batch that is ALREADY RESIDENT IN HBM:
   IQ (B, 164608) complex64 -> HIP STFT/log-mel -> (B,3,640,640) -> YOLOv11-s forward (train-mode BN) -> v8 loss
   -> backward (dgrad/wgrad/BN) -> [RCCL gradient sum when N > 1] -> unscale, clip 10, SGD-nesterov step, EMA.
-One process per GPU; for N > 1 launch with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the env).
+One process per GPU.  `python3 bench.py --gpus N` spawns its own N ranks (sy11.engine.ddp.launch: fresh child processes, started before
+this one touches the GPU); under torch.distributed.run it takes RANK / LOCAL_RANK / WORLD_SIZE from the env instead.
 Rank 0 prints ONE JSON line.
 
 Besides the headline (`value`, configs[2]) the line carries, all measured after the timed region and never part of `value`:
@@ -42,7 +43,7 @@ PROFILE_DIR = ROOT / "profiles" / "r03"
 
 # kernel family -> the C-ABI entry points that launch it, and the kernel symbols a rocprofv3 trace shows for it
 FAMILIES = {
-    "conv fwd+dgrad (dense)": {"calls": ("sy11_conv2d_fwd", "sy11_conv2d_dgrad"), "symbols": ("igemm_kernel", "igemm1x1p_kernel", "halo3x3_kernel", "halo_dgrad_s2_kernel", "smallc3x3_kernel")},
+    "conv fwd+dgrad (dense)": {"calls": ("sy11_conv2d_fwd", "sy11_conv2d_dgrad"), "symbols": ("igemm_kernel", "igemm8_kernel", "igemm1x1p_kernel", "halo3x3_kernel", "halo_dgrad_s2_kernel", "smallc3x3_kernel")},
     "conv wgrad (dense)": {"calls": ("sy11_conv2d_wgrad",), "symbols": ("wgrad16_kernel", "wgrad3x3p_kernel", "wgrad_kernel")},
     "depthwise conv": {"calls": (), "symbols": ("dw3x3_kernel", "dwconv_")},
     "batchnorm": {"calls": ("sy11_bn_act_fwd", "sy11_bn_act_bwd_reduce", "sy11_bn_act_bwd_apply", "sy11_bn_act_bwd_apply_res", "sy11_bn_finalize"),
@@ -319,6 +320,14 @@ def main():
     ap.add_argument("--leg", default="", choices=["", "predict_val"], help="run ONE reporting leg only and print its JSON (for rocprofv3 profiles of that leg)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` without a launcher: spawn one CHILD per GPU (engine/trainer.py:170-207, utils/dist.py:25-66).
+        # Nothing in this parent has touched the GPU (importing torch does not), the children are fresh interpreters and never an
+        # exec over a process that initialised the GPU; rank 0's JSON line is the children's stdout, passed through unchanged.
+        from sy11.engine.ddp import launch
+        codes = launch([str(Path(__file__).resolve()), *sys.argv[1:]], a.gpus)
+        raise SystemExit(max(codes))
+
     from sy11 import _lib
     from sy11.data.spectrogram import SpectrogramProducer
     from sy11.engine import ddp
@@ -452,7 +461,6 @@ def main():
         # kernel's own: this instrumented step launches everything on the launch stream, as `profiles/<round>/z_serial_*`
         # (the same command with SY11_WGRAD_STREAM=0) does; `z_final_*` is the headline command as it runs.
         _side_was, _engine._SIDE_WGRAD = _engine._SIDE_WGRAD, False
-        _hoist_was, _engine._HEAD_HOIST = _engine._HEAD_HOIST, False        # (the Detect levels' branch streams likewise)
         tr.model.__dict__.pop("_sy11_graph_cfg", None)          # per-launch events need individually launched kernels
         store = tr.model.__dict__.get("_sy11_grads")
         hook = module_post_backward.pop(id(store), None) if (store is not None and world > 1) else None   # the collective happened above
@@ -469,7 +477,7 @@ def main():
         step()
         torch.cuda.synchronize()
         prof, _lib.PROFILE = _lib.PROFILE, None
-        _engine._SIDE_WGRAD, _engine._HEAD_HOIST = _side_was, _hoist_was
+        _engine._SIDE_WGRAD = _side_was
         pair_ms = sorted(c0.elapsed_time(c1) for c0, c1 in empty)[len(empty) // 2]
         if hook is not None:
             module_post_backward[id(store)] = hook
@@ -524,7 +532,7 @@ def main():
             if rows:
                 top = max(rows, key=lambda r: float(r["ms_per_step"]))
                 dominant = {"symbol": top["kernel"], "launches_per_step": float(top["launches_per_step"]), "ms_per_step": float(top["ms_per_step"]),
-                            "avg_us_per_launch": float(top["avg_us_per_launch"]), "source": f"profiles/{PROFILE_DIR.name}/{kcsv.name} (rocprofv3 --kernel-trace --stats of this command, kernels one at a time: SY11_WGRAD_STREAM=0 SY11_HEAD_HOIST=0)"}
+                            "avg_us_per_launch": float(top["avg_us_per_launch"]), "source": f"profiles/{PROFILE_DIR.name}/{kcsv.name} (rocprofv3 --kernel-trace --stats of this command, kernels one at a time: SY11_WGRAD_STREAM=0)"}
         roof = {"kernel": name, "kernel_symbols": list(FAMILIES.get(name, {}).get("symbols", ())), "dominant_symbol": dominant,
                 "bound": "hbm" if hbm_bound else "mfma",
                 "achieved": round(ach_gb, 1) if hbm_bound else round(ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,

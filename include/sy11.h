@@ -77,6 +77,10 @@ int sy11_tune_clear(void);
 /* Measurement helper (bench.py `peaks`): a pure-MFMA loop, `iters` x 8 v_mfma_f32_32x32x16_f16 per wave, 4 waves per
  * workgroup, no memory traffic.  FLOPs per launch = workgroups * 4 * iters * 8 * 32768; out: workgroups * 4 floats.     */
 int sy11_peak_mfma_f16(int32_t workgroups, int32_t iters, float* out, void* stream);
+/* Diagnostic (tools/igemm8_stamps.py, never on the product path): with SY11_IGEMM_DEBUG=9 the 8-wave convolution pipeline
+ * (csrc/igemm8.hip) sums per-section s_memtime deltas in waves 0 / 4 of workgroup 0; this copies the 2 x 8 counters of the
+ * last such launch to the HOST array out16 (synchronous).                                                             */
+int sy11_debug_stamps(uint64_t* out16);
 
 /* ---- convolution (replaces nn.Conv2d inside Conv.forward / forward_fuse, nn/modules/conv.py:79-83,
  *      and the bare nn.Conv2d heads of Detect, nn/modules/head.py:44-55) -------------------------------- */
@@ -302,7 +306,7 @@ typedef struct sy11_opt_desc {
   int64_t n_buf;               /* elements of buf / ema_buf (BatchNorm running statistics), may be 0             */
   int64_t group_end[3];        /* end of each parameter group inside the flat buffers                            */
   float lr[3], momentum[3], weight_decay[3];    /* AdamW: momentum = beta1                                      */
-  int32_t kind;                /* 0 SGD nesterov (dampening 0), 1 AdamW                                          */
+  int32_t kind;                /* 0 SGD nesterov (dampening 0), 1 AdamW (decoupled decay), 2 Adam (L2 in the gradient) */
   float beta2, eps;            /* AdamW                                                                          */
   float max_norm;              /* clip_grad_norm_ threshold (10.0)                                               */
   float ema_decay;             /* d of this update: ema = d * ema + (1 - d) * value                              */

@@ -515,8 +515,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // 15, 16 = halo-tiled 3x3 kernel (conv3x3.hip) with the widest / the next narrower channel tile
 // 17, 18 = the same with 256-pixel tiles (stride 1): half the filter bytes per FLOP
 // 19 = few-channel 3x3 stride-1 kernel (conv3x3s.hip): C = 16 / 32, N <= 32, the filter resident in registers
+// 20, 21 = 8-wave phase-staggered pipeline (igemm8.hip): 256 pixels x 128 / 64 channels, 128-byte K stages, one workgroup per CU
 constexpr int IGEMM_NCFG = SY11_IGEMM_NCFG;
-static_assert(IGEMM_NCFG == 20, "configuration table and its size (tune.h) out of step");
+static_assert(IGEMM_NCFG == 22, "configuration table and its size (tune.h) out of step");
+bool sy11_igemm8_legal(const IgemmArgs& a, int bn, int epi);
+int sy11_igemm8_launch(const IgemmArgs& a, int bn, int epi, hipStream_t st);
 static int halo_bn(const IgemmArgs& a, int cfg) {
   const int wide = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   const int bn = (cfg == 15 || cfg == 17) ? wide : (wide > 32 ? wide / 2 : 0);
@@ -537,6 +540,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
     return std::is_same<T, _Float16>::value && bn > 0 && sy11_halo3x3_legal(a, bn);
   }
   if (cfg == 19) return !std::is_same<T, float>::value && sy11_smallc3x3_legal(a);
+  if (cfg == 20 || cfg == 21) return std::is_same<T, _Float16>::value && sy11_igemm8_legal(a, cfg == 20 ? 128 : 64, epi_code(a));
   if (cfg == 7 || cfg == 8) {
     const int epi = epi_code(a), bn = cfg == 7 ? 128 : 64;
     if (std::is_same<T, float>::value || a.T != 1 || a.tap_dy[0] || a.tap_dx[0] || a.sy != 1 || a.sx != 1 || !a.dense_out || !a.vec_out) return false;
@@ -564,8 +568,9 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
   if (cfg == 7 || cfg == 8)
     return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
                                  a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st, a.bias);
-  const int bm = cfg == 3 ? 256 : 128;
-  const int tile = cfg >= 12 ? cfg - 12 : (cfg >= 9 ? cfg - 9 : (cfg >= 4 ? cfg - 4 : cfg));
+  const bool wave8 = cfg == 20 || cfg == 21;
+  const int bm = (cfg == 3 || wave8) ? 256 : 128;
+  const int tile = wave8 ? cfg - 20 : (cfg >= 12 ? cfg - 12 : (cfg >= 9 ? cfg - 9 : (cfg >= 4 ? cfg - 4 : cfg)));
   const int bn = tile == 1 ? 64 : (tile == 2 ? 32 : 128);
   a.tiles_n = cdiv(a.N, bn);
   const long nwg = (long)cdiv(a.M, bm) * a.tiles_n;
@@ -608,7 +613,10 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
       default: SY11_IGV(BNN, WMM, WNN, -1); break;               \
     }                                                            \
   } while (0)
-  if (bm == 256) {
+  if (wave8) {
+    const int rc8 = sy11_igemm8_launch(a, bn, epi_pre, st);
+    if (rc8) return rc8;
+  } else if (bm == 256) {
     if constexpr (std::is_same<T, _Float16>::value) {
       if (epi_pre == 0) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 0>), grid, block, 0, st, a);
       else if (epi_pre == 1) hipLaunchKernelGGL((igemm_kernel<T, 256, 128, 2, 2, 64, 3, 1>), grid, block, 0, st, a);
@@ -661,9 +669,9 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
     } else if (sy11tune::enabled() && !sy11tune::capturing(st)) {
       int cands[IGEMM_NCFG], nc = 0;
       for (int c = 0; c < IGEMM_NCFG; ++c) {
-        const int ct = c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c)));
+        const int ct = c >= 20 ? c - 20 : (c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c))));
         const int cbn = ct == 1 ? 64 : (ct == 2 ? 32 : 128);
-        if (c < 15 && cbn > 32 && cbn >= 2 * a.N) continue;              // tile more than twice the channel count: pure waste
+        if ((c < 15 || c >= 20) && cbn > 32 && cbn >= 2 * a.N) continue;              // tile more than twice the channel count: pure waste
         if (cfg_legal<T>(a, c)) cands[nc++] = c;
       }
       // measuring must leave no trace: no BN statistics; an accumulating epilogue runs with its global stores disabled

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const OptArgs a, int para
   // bias corrections (AdamW): the step this update is (count of non-skipped steps so far + 1)
   const float t = a.ws[1] + 1.f;
   float bc1[3], bc2s = 1.f;
-  if (a.kind == 1) {
+  if (a.kind != 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) bc1[k] = 1.f - powf(a.grp[k].momentum, t);
     bc2s = sqrtf(1.f - powf(a.beta2, t));
@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const OptArgs a, int para
         float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float g = gv[q];
-          pv[q] *= 1.f - lr * wd;                          // decoupled decay
+          float g = gv[q];
+          if (a.kind == 1) pv[q] *= 1.f - lr * wd;         // AdamW: decoupled decay
+          else if (wd != 0.f) g += wd * pv[q];             // torch.optim.Adam (kind 2): L2 joins the gradient before the moments
           const float mn = mom * mv[q] + (1.f - mom) * g;
           const float vn = a.beta2 * vv[q] + (1.f - a.beta2) * g * g;
           mv[q] = mn; vv[q] = vn;
@@ -169,7 +170,8 @@ extern "C" int sy11_opt_step(const sy11_opt_desc* d, float* param, float* grad, 
                              void* stream) {
   SY11_REQUIRE(d && param && grad && mom && ws, "opt_step: null pointer");
   SY11_REQUIRE(d->n > 0 && d->n % 4 == 0 && d->nparts > 0 && d->nparts <= 4096, "opt_step: bad n / nparts");
-  SY11_REQUIRE(d->kind == 0 || (d->kind == 1 && sq && adam_step), "opt_step: kind must be 0 (SGD) or 1 (AdamW, needs `sq` and `adam_step`)");
+  SY11_REQUIRE(d->kind == 0 || ((d->kind == 1 || d->kind == 2) && sq && adam_step),
+               "opt_step: kind must be 0 (SGD), 1 (AdamW) or 2 (Adam, coupled L2); 1 and 2 need `sq` and `adam_step`");
   SY11_REQUIRE(d->n_buf == 0 || (buf && ema_buf && ema), "opt_step: buffers given without their EMA");
   SY11_REQUIRE(!d->amp || (scale && growth_tracker), "opt_step: amp needs the scale and growth-tracker scalars");
   for (const void* q : {(const void*)param, (const void*)grad, (const void*)mom, (const void*)ema, (const void*)sq})

@@ -441,6 +441,32 @@ def _worker_main(payload, wid, seed, tasks, results):
             results.put((gen, bid, None, f"{e!r}\n{traceback.format_exc()}"))
 
 
+class _main_not_reimported:
+    """While worker processes are started: hide ``__main__``'s file / spec from multiprocessing's spawn bootstrap.  A spawned child
+    otherwise re-runs the parent's main script as ``__mp_main__`` — a training script without an ``if __name__ == '__main__'`` guard
+    (fine with the reference's fork workers) would call ``train()`` again inside every loader worker (a second process group on the
+    inherited RANK / MASTER_PORT, GPU work in a worker) and the worker would die in its bootstrap.  The worker entry point and the
+    pickled dataset live in importable sy11 modules; nothing of ``__main__`` is needed there."""
+
+    def __enter__(self):
+        import sys
+        self.main = sys.modules.get("__main__")
+        self.saved = {}
+        if self.main is not None:
+            for k in ("__file__", "__spec__"):
+                if k in self.main.__dict__:
+                    self.saved[k] = self.main.__dict__[k]
+            self.main.__dict__.pop("__file__", None)
+            self.main.__dict__["__spec__"] = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.main is not None:
+            self.main.__dict__.pop("__spec__", None)
+            self.main.__dict__.update(self.saved)
+        return False
+
+
 class WorkerLoader(InfiniteDataLoader):
     """InfiniteDataLoader whose per-sample Python runs in ``procs`` worker processes (data/build.py:129-157 `workers`).
 
@@ -461,8 +487,9 @@ class WorkerLoader(InfiniteDataLoader):
         self.tasks = [ctx.Queue() for _ in range(self.procs)]
         self.workers = [ctx.Process(target=_worker_main, args=(payload, w, 1000003 * (seed + 1) + 7919 * max(rank, 0), self.tasks[w], self.results), daemon=True)
                         for w in range(self.procs)]
-        for p in self.workers:
-            p.start()
+        with _main_not_reimported():
+            for p in self.workers:
+                p.start()
         self.generation = 0
         self.materialize = Materializer(self._fetch, dataset.device)
         self._closed = False
@@ -529,7 +556,10 @@ class WorkerLoader(InfiniteDataLoader):
                 # decoding / uploading the source files of EVERY arrived recipe at once: the files of batches k+1, k+2, ... are read
                 # while batch k trains
                 try:
-                    g, bid, samples, err = self.results.get(block=want not in ready)
+                    if want in ready:
+                        g, bid, samples, err = self.results.get(block=False)
+                    else:
+                        g, bid, samples, err = self._get_or_raise()
                 except queue.Empty:
                     break
                 if g != gen:
@@ -541,6 +571,18 @@ class WorkerLoader(InfiniteDataLoader):
                     self._start_decodes(samples)
                 ready[bid] = samples
             yield ready.pop(pending.pop(0))
+
+    def _get_or_raise(self, poll=2.0):
+        """Blocking read of the result queue that notices a dead worker (a crash in its bootstrap, an unpicklable dataset, the OOM
+        killer): a plain ``get()`` would wait forever for the batch that worker owed."""
+        while True:
+            try:
+                return self.results.get(timeout=poll)
+            except queue.Empty:
+                dead = [(w, p.exitcode) for w, p in enumerate(self.workers) if not p.is_alive()]
+                if dead:
+                    raise RuntimeError("loader worker process(es) died: " + ", ".join(f"worker {w} exit code {c}" for w, c in dead) +
+                                       " (run with workers=0 / SY11_LOADER_PROCS=0 for the in-process pipeline)") from None
 
     def _forever(self):
         for samples in self._recipes():

@@ -125,18 +125,10 @@ def _side_stream(device):
 # per step with the branches against 22.40 / 22.38 ms on one stream — as with the filter-gradient stream above, parallel branches
 # of a hipGraph cost more than the idle CUs they fill.  SY11_BRANCH_STREAMS=1 turns it on.
 _BRANCH_STREAMS_ON = os.environ.get("SY11_BRANCH_STREAMS", "0") != "0"
-# The Detect chains of a level launched as soon as that level's feature map exists (BaseModel._run), on the level's branch
-# stream: the stride-8 level's six 80x80 convolutions then run beside the 40x40 / 20x20 neck layers 17-22 that follow its input,
-# instead of after them (forward; in the backward pass a level's closures keep their place in the tape and run on the branch
-# stream between the main-stream closures around them).  Implies the branch streams.  Same-box A/B, two pairs: 19.61 / 19.71 ms
-# without, 19.52 / 19.43 with (-0.9 %, box-to-box spread is larger).  OFF by default (SY11_HEAD_HOIST=1 turns it on): it REORDERS
-# the sums into a level's input gradient (the next neck layer's input gradient now arrives before the level's own chains'), so an
-# ordered-mode step differs in the last bits from the un-hoisted one in every layer below the hoist points and in none above
-# them, and two hoisted runs are bit-identical (tools/hoist_debug.py) — not a race, but no longer the reference's order of
-# additions either.  And it is NOT clean on every graph: with it on, the whole `-m gpu` suite passes except the fusion variant's
-# f16 parity test, where the filters of model.15 (the stride-8 level's source there) land 6 % from the emulation AND from the f32
-# gradient (device 6.1e-2, emulation 4.5e-3) — unexplained, so the engine keeps the head where the reference has it.
-_HEAD_HOIST = os.environ.get("SY11_HEAD_HOIST", "0") != "0"
+# (r03 also carried SY11_HEAD_HOIST=1 — the Detect chains of the stride-8 / 16 levels launched as soon as their feature map existed, beside
+# the neck layers that follow it: -0.9 % in a same-box A/B, but it broke _Branch's contract below (main-stream launches inside an open
+# branch section) and the fusion variant's f16 parity test failed with it on (model.15's filter / BN-weight gradients 6 % / 11 % off).
+# r04 removed it: a 1 % lever with a known wrong answer is not worth carrying; multi-problem launches are the replacement.)
 _BRANCH_STREAMS = {}
 
 
@@ -162,7 +154,8 @@ class _Branch:
         self.start = len(ec.tape)
         if ec.use_branches:
             st = _branch_stream(ec.device, self.b)
-            st.wait_stream(torch.cuda.current_stream(ec.device))
+            ec.main_stream = torch.cuda.current_stream(ec.device)
+            st.wait_stream(ec.main_stream)
             self.cm = torch.cuda.stream(st)
             self.cm.__enter__()
             ec.open_branches.add(self.b)
@@ -204,9 +197,9 @@ class Ctx:
         self.side = None
         self.side_refs: List = []
         self.use_side = _SIDE_WGRAD and device is not None and torch.device(device).type == "cuda"
-        self.hoist_head = _HEAD_HOIST and device is not None and torch.device(device).type == "cuda"
-        self.use_branches = (_BRANCH_STREAMS_ON or self.hoist_head) and device is not None and torch.device(device).type == "cuda"
+        self.use_branches = _BRANCH_STREAMS_ON and device is not None and torch.device(device).type == "cuda"
         self.open_branches = set()
+        self.main_stream = None           # the stream a branch section was entered from (set while any branch is open)
         self.tape_branches: List = []     # (first tape index, end, branch) of the closures recorded inside a branch section
 
     def on_side(self, fn, *keep):
@@ -224,10 +217,20 @@ class Ctx:
             self.flush_side()
 
     def flush_side(self):
-        """Fork: everything queued so far runs on the side stream, ordered after what the current stream has issued."""
+        """Fork: everything queued so far runs on the side stream, ordered after what EVERY stream of this pass has issued: the
+        current one, the main stream when the flush happens inside a branch closure, and every branch still open (the
+        32nd launch of a batch may be queued inside a branch closure — the batch also holds launches whose operands were produced on
+        the main stream or on a sibling branch, and waiting for the current stream alone does not order those)."""
         if self.side is None or not self.side_queue:
             return
-        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(cur)
+        if self.main_stream is not None and self.main_stream != cur:
+            self.side.wait_stream(self.main_stream)
+        for b in sorted(self.open_branches):
+            st = _branch_stream(self.device, b)
+            if st != cur:
+                self.side.wait_stream(st)
         with torch.cuda.stream(self.side):
             for fn in self.side_queue:
                 fn()
@@ -261,7 +264,8 @@ class Ctx:
             else:
                 st = _branch_stream(self.device, b)
                 if b not in self.open_branches:
-                    st.wait_stream(torch.cuda.current_stream(self.device))
+                    self.main_stream = torch.cuda.current_stream(self.device)
+                    st.wait_stream(self.main_stream)
                     self.open_branches.add(b)
                 with torch.cuda.stream(st):
                     self.tape[idx]()

@@ -163,6 +163,38 @@ def share_tuner_picks(src: int = 0, group=None):
     return len(box[0]) // 16
 
 
+_CTL_GROUP = None
+
+
+def control_group():
+    """A host-side (gloo) group next to the RCCL one, for the few per-step CONTROL decisions every rank must take identically.
+    A collective on it blocks only the host thread — which runs a step ahead of the GPU — never the launch stream, and needs no
+    device synchronisation to read its result.  Collective: created on first use by all ranks together."""
+    global _CTL_GROUP
+    if not dist.is_initialized() or dist.get_world_size() <= 1:
+        return None
+    if _CTL_GROUP is None:
+        _CTL_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _CTL_GROUP
+
+
+def share_tuner_picks_if_any(local_flag: bool, src: int = 0) -> bool:
+    """Rank-uniform trigger for share_tuner_picks().  Every rank calls this EVERY training step with its own flag ("this step ran
+    eagerly and may have added picks"); the flags are MAX-reduced on the control group, so either all ranks enter the broadcast
+    or none does.  (r03 decided from a rank-local counter keyed on the input signature: with `multi_scale`, where every rank
+    draws its own image size — random.randrange under seed + 1 + RANK — or an uneven last batch, one rank called the broadcast
+    while another went on to the gradient all-reduce: mismatched collectives.)"""
+    g = control_group()
+    if g is None:
+        return False
+    t = torch.tensor([1 if local_flag else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=g)
+    if int(t.item()) == 0:
+        return False
+    share_tuner_picks(src)
+    return True
+
+
 def free_port() -> int:
     """A free TCP port on the loopback interface (utils/dist.py:13-22 find_free_network_port)."""
     import socket

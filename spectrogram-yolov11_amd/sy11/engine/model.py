@@ -182,12 +182,14 @@ class YOLO:
         kw = {**kw, "save_dir": save_dir, "data": kw["data"] if isinstance(kw["data"], dict) else str(kw["data"])}
         payload = {"pkg": str(Path(__file__).resolve().parents[2]), "model": self.model_name, "nc": getattr(self.model.model[-1], "nc", None),
                    "kw": kw}
+        # guarded: anything that re-imports this file as a module (multiprocessing's spawn bootstrap does) must not train again
         src = ("import json, sys\n"
-               f"P = json.loads({json.dumps(json.dumps(payload, default=str))})\n"
-               "sys.path.insert(0, P['pkg'])\n"
-               "from sy11.engine.model import YOLO\n"
-               "m = YOLO(P['model'], nc=P['nc']) if str(P['model']).endswith(('.yaml', '.yml')) else YOLO(P['model'])\n"
-               "m.train(**P['kw'])\n")
+               "if __name__ == '__main__':\n"
+               f"    P = json.loads({json.dumps(json.dumps(payload, default=str))})\n"
+               "    sys.path.insert(0, P['pkg'])\n"
+               "    from sy11.engine.model import YOLO\n"
+               "    m = YOLO(P['model'], nc=P['nc']) if str(P['model']).endswith(('.yaml', '.yml')) else YOLO(P['model'])\n"
+               "    m.train(**P['kw'])\n")
         with tempfile.NamedTemporaryFile("w", suffix=".py", prefix="_sy11_ddp_", delete=False) as f:
             f.write(src)
         vis = ",".join(str(d) for d in devices)

@@ -154,7 +154,9 @@ class DetectionTrainer:
         from .. import ops as K
         n = self.flat.flat.numel()
         adam = type(self.optimizer).__name__ != "SGD"
-        self._opt_kind = 1 if adam else 0
+        # 0 SGD-nesterov, 1 AdamW (decoupled decay), 2 Adam (torch.optim.Adam: the weight group's decay is L2 ADDED TO THE GRADIENT
+        # before the moments — the reference's build_optimizer gives 'Adam' exactly that; r03 ran it through the AdamW rule)
+        self._opt_kind = {"SGD": 0, "AdamW": 1, "Adam": 2}[type(self.optimizer).__name__]
         self._opt_mom = torch.zeros(n, dtype=torch.float32, device=self.device)
         self._opt_sq = torch.zeros(n, dtype=torch.float32, device=self.device) if adam else None
         self._adam_step = torch.zeros((), dtype=torch.float32, device=self.device) if adam else None
@@ -434,14 +436,13 @@ class DetectionTrainer:
         if self.world_size > 1 and self.device.type == "cuda":
             # Rank 0 alone measures tile configurations, and it measures per PROBLEM, on the first eager call that meets it:
             # the first two steps of every input signature (a new image size, the short last batch of an epoch, the first
-            # steps after a resume) run eagerly and may add picks, the third is captured.  So the tables are shared after each
-            # of those two steps — a rule every rank evaluates identically from its own inputs (the ranks of a data-parallel
-            # job see the same sequence of batch shapes), independent of the global step counter `ni` (which a resumed run
-            # starts at start_epoch * nb).  Ranks >= 1 never measure (`tune` stays 0 there by design).
+            # steps after a resume) run eagerly and may add picks, the third is captured.  Whether THIS rank just ran such a
+            # step is a rank-local fact (multi_scale draws a size per rank; last batches can differ), so the decision to
+            # broadcast is itself agreed on first: one MAX all-reduce of the flag on the host-side control group per step
+            # (ddp.share_tuner_picks_if_any) — all ranks share, or none does.  Ranks >= 1 never measure (`tune` 0 by design).
             img = batch["img"]
             sig = (tuple(img.shape), img.dtype, self.model._sy11_dtype)
             n = self._sig_runs.get(sig, 0) + 1
             self._sig_runs[sig] = n
-            if n <= 2:
-                ddp.share_tuner_picks()                          # collective
+            ddp.share_tuner_picks_if_any(n <= 2)                 # collective, every step, on every rank
         return loss.detach(), items

@@ -92,15 +92,11 @@ class Detect(nn.Module):
         self._branch(ec, self.cv3[i], x, m.slice(4 * self.reg_max, self.no))
         return m
 
-    def _run(self, ec: Ctx, xs, pre=None):
-        """``pre``: {level: map} of levels BaseModel._run already launched on their branch streams (head hoisting)."""
+    def _run(self, ec: Ctx, xs):
         if self.end2end:
             raise ops._lib.Sy11Error("end2end (v10) heads are outside the hot path")
         maps = []
         for i in range(self.nl):                                # the levels are independent: one stream (graph branch) each
-            if pre and i in pre:
-                maps.append(pre[i])
-                continue
             with ec.branch(i):
                 maps.append(self._level(ec, i, xs[i]))
         ec.join_branches()

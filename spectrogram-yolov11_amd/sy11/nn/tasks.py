@@ -85,11 +85,6 @@ class BaseModel(nn.Module):
         cats = {}
         y = []
         split = self.__dict__.get("_sy11_bucket_layer")     # data parallel: gradients of layers >= split form the first bucket
-        det = self.model[-1]
-        hoist_at, pre = {}, {}
-        if getattr(ec, "hoist_head", False) and isinstance(det, Detect) and not det.end2end and isinstance(det.f, (list, tuple)):
-            # all but the last source of the head: that one's level starts where the head itself would start anyway
-            hoist_at = {j: lvl for lvl, j in enumerate(det.f[:-1]) if isinstance(j, int) and 0 <= j < det.i - 1}
         for m in self.model:
             if m.i == split and ec.record:
                 ec.marks["bucket"] = len(ec.tape)
@@ -113,13 +108,8 @@ class BaseModel(nn.Module):
                 x = cats[m.i]                       # every source already lives in this buffer
             elif out is not None:
                 x = m._run(ec, x, out=out)
-            elif m is det and pre:
-                x = m._run(ec, x, pre=pre)
             else:
                 x = m._run(ec, x)
-            if m.i in hoist_at:                                 # this level's chains start now, beside the layers that follow
-                with ec.branch(hoist_at[m.i]):
-                    pre[hoist_at[m.i]] = det._level(ec, hoist_at[m.i], x)
             y.append(x if m.i in self.save else None)
         return x
 

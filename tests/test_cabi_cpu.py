@@ -103,7 +103,11 @@ def test_tune_import_accepts_every_configuration_of_this_build_and_nothing_beyon
     added to the kernels while the importer still had the old sizes — rank 0's picks then failed to import on the other ranks.)"""
     import struct
     from sy11 import _lib
-    igemm_n, wgrad_n = 20, 16
+    import re
+    tune_h = (ROOT / "spectrogram-yolov11_amd" / "csrc" / "tune.h").read_text()
+    igemm_n = int(re.search(r"SY11_IGEMM_NCFG = (\d+);", tune_h).group(1))
+    wgrad_n = int(re.search(r"SY11_WGRAD_NCFG = (\d+);", tune_h).group(1))
+    assert igemm_n >= 22 and wgrad_n >= 16                    # r04: the 8-wave pipeline added configurations 20 / 21
     _lib.tune_import(struct.pack("<Qii", 0xfeed0001, 0, igemm_n - 1) + struct.pack("<Qii", 0xfeed0002, 1, wgrad_n - 1))
     blob = _lib.tune_export()
     recs = {blob[i:i + 16] for i in range(0, len(blob), 16)}

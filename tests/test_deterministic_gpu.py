@@ -119,7 +119,6 @@ def test_filter_gradient_stream_does_not_change_an_ordered_run(deterministic, mo
     def run(batch_per_fork):
         monkeypatch.setattr(E, "_SIDE_WGRAD", batch_per_fork > 0)
         monkeypatch.setattr(E, "_SIDE_BATCH", max(batch_per_fork, 1))
-        monkeypatch.setattr(E, "_HEAD_HOIST", False)    # (early Detect levels REORDER the sums into a level's input gradient: not bit-comparable)
         torch.manual_seed(4)
         m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
         if not amp:                                     # (AMP: the constructor's initialisation, as in the test above)
@@ -149,14 +148,13 @@ def test_filter_gradient_stream_in_eager_steps(deterministic, monkeypatch, mode)
     if mode == "atomic":
         _lib.set_option("deterministic", 0)
 
-    def run(n, hoist=False):
+    def run(n):
         monkeypatch.setattr(E, "_SIDE_WGRAD", n > 0)
         monkeypatch.setattr(E, "_SIDE_BATCH", max(n, 1))
-        monkeypatch.setattr(E, "_HEAD_HOIST", hoist)
         return _one_step("yolo11n.yaml", layers, 80, torch.float32, batch)
     ref = run(0)
-    for n, hoist in ((1, False), (5, False)):                     # head hoisting in eager steps: see sy11/engine/__init__.py (_HEAD_HOIST)
-        got = run(n, hoist)
+    for n in (1, 5):
+        got = run(n)
         if mode == "ordered":
             assert _same(got[2], ref[2]) and _same(got[0], ref[0]), f"{n} per fork: {int((got[2] != ref[2]).sum())} gradient elements differ"
         else:

@@ -440,6 +440,18 @@ DDP_TRAINER_SCRIPT = textwrap.dedent("""
         _lib.tune_import(struct.pack("<Qii", 1, 0, 1))
     assert ddp.share_tuner_picks() == 2
     assert sorted(_lib.tune_export()[i:i + 16] for i in (0, 16)) == sorted([struct.pack("<Qii", 4242, 0, 3), struct.pack("<Qii", 77, 1, 9)])
+    # ... and the trigger is rank-uniform (ADVICE r03): flags that differ across ranks (multi_scale sizes drawn per rank, an uneven
+    # last batch) must never leave one rank in the broadcast and the other in the gradient all-reduce
+    _lib.load().sy11_tune_clear()
+    if rank == 0:
+        _lib.tune_import(struct.pack("<Qii", 5, 0, 2))
+    for step_flags in ((False, False), (True, False), (False, True), (True, True), (False, False)):
+        shared = ddp.share_tuner_picks_if_any(step_flags[rank])
+        assert shared == any(step_flags), (step_flags, shared)
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)                                   # the next collective of a step lines up on both ranks
+        assert probe.item() == 3.0
+    assert _lib.tune_export() == struct.pack("<Qii", 5, 0, 2)
     # early stopping: only rank 0 knows the fitness, everybody must leave fit() together (engine/trainer.py:456-461)
     class Loader:
         dataset = None

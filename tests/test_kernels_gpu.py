@@ -169,7 +169,7 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
     tune0 = _lib.get_option("tune")
     try:
         _lib.set_option("tune", 0)
-        for cfg in range(20):
+        for cfg in range(22):
             _lib.set_option("igemm_cfg", cfg)
             y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
             ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
@@ -234,6 +234,66 @@ def test_few_channel_conv_epilogues_and_bf16(case, dtype):
         close(to_nchw(dx), 2 * ref_dx, dtype, "dgrad accumulate", mult=2)
     finally:
         _lib.set_option("igemm_cfg", -1)
+
+
+@pytest.mark.parametrize("case", [
+    # B, C, H, W, N, k, s  — every case is LEGAL for the 8-wave pipeline (M >= 256, K >= 128, N > 32): a forced illegal cfg would fall back silently
+    (2, 96, 24, 20, 160, 3, 1),      # cfg 20: partial pixel tile (960 rows), partial channel tile (160 = 128 + 32), K = 864 = 13.5 stages
+    (1, 40, 18, 30, 72, 3, 2),       # cfg 20: C = 40 < one stage (several taps per stage, the per-chunk tap walk), stride 2, N = 72
+    (3, 512, 10, 10, 128, 1, 1),     # cfg 20: 1x1, 8 stages, 300 rows
+    (1, 64, 16, 32, 136, 3, 1),      # cfg 20: exactly two pixel tiles, 9 stages (ring wraps three times), N = 136
+    (2, 128, 20, 20, 64, 3, 1),      # cfg 21: 64-channel tile
+    (1, 192, 40, 40, 48, 1, 1),      # cfg 21: N = 48 (partial 64-tile), K = 192 = 3 stages
+    (2, 64, 13, 11, 128, 1, 1),      # cfg 20: K = 64: ONE stage... below the legal K (falls back): the dispatcher must refuse, not misbehave
+    (1, 128, 16, 16, 256, 1, 1),     # cfg 20: K = 128 = two stages, exactly one pixel tile, two channel tiles
+])
+def test_eight_wave_pipeline_epilogues_and_tails(case):
+    """igemm configurations 20 / 21 (igemm8.hip): the four epilogues it carries — BN statistics (training forward), none and accumulate
+    (input gradients), bias + SiLU (the fused inference conv) — into channel slices of wider tensors (concat by pointer), with
+    ragged pixel / channel / K tails, tap-major and channel-major K order."""
+    from sy11 import _lib
+    o = ops()
+    dtype = torch.float16
+    B, Cn, H, W, N, k, s = case
+    p = k // 2
+    x = rnd(B, Cn, H, W, seed=51)
+    w = rnd(N, Cn, k, k, seed=52, scale=1.0 / math.sqrt(Cn * k * k))
+    bias = rnd(N, seed=53, scale=0.5)
+    xq, wq = q(x, dtype), q(w, dtype)
+    OH, OW = o.conv_out_hw(H, W, k, s, p)
+    wk = wq.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    ref = F.conv2d(xq, wq, None, s, p)
+    xv = nhwc(x, dtype, 16)                                     # a channel slice: pixel stride C + 16
+    dy = rnd(B, N, OH, OW, seed=54)
+    ref_dx = torch.nn.grad.conv2d_input((B, Cn, H, W), wq, q(dy, dtype), s, p)
+    wt = o.weight_transpose(wk)
+    cfg = 20 if N > 64 else 21
+    korder0 = _lib.get_option("igemm_korder")
+    try:
+        for korder in (1, 0):
+            _lib.set_option("igemm_korder", korder)
+            _lib.set_option("igemm_cfg", cfg)
+            wide_y = torch.full((B, OH, OW, N + 24), 7.0, dtype=dtype, device=DEV)
+            yv = wide_y[..., 16:16 + N]
+            ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+            o.conv2d_fwd(xv, wk, yv, k, s, p, stats=(ssum, ssq))
+            close(to_nchw(yv), ref, dtype, f"fwd into a slice (korder {korder})")
+            assert bool((wide_y[..., :16] == 7.0).all()) and bool((wide_y[..., 16 + N:] == 7.0).all())
+            close(ssum.cpu(), ref.sum((0, 2, 3)), dtype, "statistics", mult=4 * math.sqrt(B * OH * OW))
+            close(ssq.cpu(), (ref * ref).sum((0, 2, 3)), dtype, "statistics sq", mult=8)
+            y2 = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
+            o.conv2d_fwd(xv, wk, y2, k, s, p, bias=bias.to(DEV), silu=True)
+            close(to_nchw(y2), F.silu(ref + bias.view(1, -1, 1, 1)), dtype, "bias + SiLU", mult=2)
+            # input gradient: the same kernel on dy (C and N swap roles: legal when C > 32 ... ) — plain, then accumulated
+            _lib.set_option("igemm_cfg", 20 if Cn > 64 else 21)
+            dx = torch.zeros(B, H, W, Cn, dtype=dtype, device=DEV)
+            o.conv2d_dgrad(nhwc(dy, dtype), wt, dx, (B, OH, OW, N), k, s, p, accumulate=(s > 1))
+            close(to_nchw(dx), ref_dx, dtype, f"dgrad (korder {korder})")
+            o.conv2d_dgrad(nhwc(dy, dtype), wt, dx, (B, OH, OW, N), k, s, p, accumulate=True)
+            close(to_nchw(dx), 2 * ref_dx, dtype, "dgrad accumulate", mult=2)
+    finally:
+        _lib.set_option("igemm_cfg", -1)
+        _lib.set_option("igemm_korder", korder0)
 
 
 @pytest.mark.parametrize("case", [(2, 64, 10, 80, 64), (1, 32, 8, 160, 16), (2, 128, 20, 20, 96), (1, 48, 12, 40, 72)])

@@ -76,3 +76,50 @@ def test_batches_arrive_in_order_from_several_workers_and_close_mosaic_reaches_t
     # rect / validation datasets and workers <= 1 stay in-process
     from sy11.data.dataset import InfiniteDataLoader
     assert type(build_dataloader(ds, 4, workers=1)) is InfiniteDataLoader
+
+
+def test_unguarded_main_script_is_not_rerun_in_the_workers(tmp_path):
+    """a spawned worker re-imports the parent's main script; a script without an `if __name__ == '__main__'` guard
+    (fine with the reference's fork workers) then ran its top level again inside every worker, the worker died in its bootstrap and
+    the training process waited forever.  The workers are started with `__main__` hidden from the spawn bootstrap: the very same
+    unguarded script must finish, and its top level must have run exactly once."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    make_dataset(tmp_path)
+    marker = tmp_path / "runs.txt"
+    script = tmp_path / "train_unguarded.py"
+    script.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {str(root / 'spectrogram-yolov11_amd')!r})\n"
+        f"open({str(marker)!r}, 'a').write('x')\n"                                      # top level: once per (re-)execution
+        "from sy11.data.dataset import WorkerLoader, YOLODataset\n"
+        f"ds = YOLODataset({str(tmp_path / 'images')!r}, imgsz=64, augment=True, batch_size=4, data={{'nc': 2}}, device='cpu')\n"
+        "dl = WorkerLoader(ds, 4, procs=2, shuffle=False, seed=1)\n"
+        "it = dl._recipes()\n"
+        "n = sum(len(next(it)) for _ in range(3))\n"
+        "dl.close()\n"
+        "print('samples', n)\n")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "samples 12" in r.stdout
+    assert marker.read_text() == "x"
+
+
+def test_a_dead_worker_raises_instead_of_hanging(tmp_path):
+    from sy11.data.dataset import WorkerLoader
+    ds = make_dataset(tmp_path)
+    dl = WorkerLoader(ds, 4, procs=2, shuffle=False, seed=1)
+    try:
+        it = dl._recipes()
+        next(it)
+        for p in dl.workers:
+            p.kill()                                             # exact PIDs this loader started
+        for p in dl.workers:
+            p.join(timeout=10)
+        with pytest.raises(RuntimeError, match="died"):
+            for _ in range(16):                                  # whatever was already queued is delivered; then the loss is noticed
+                next(it)
+    finally:
+        dl.close()

@@ -70,7 +70,7 @@ def test_accumulation_window_and_grad_views():
     assert gs.flat.abs().sum() == 0                                # gradients cleared after the optimizer step
 
 
-@pytest.mark.parametrize("opt", [{}, {"optimizer": "auto", "iterations": 500}])
+@pytest.mark.parametrize("opt", [{}, {"optimizer": "auto", "iterations": 500}, {"optimizer": "Adam", "lr0": 1e-4, "weight_decay": 0.05}])
 def test_flat_state_matches_per_tensor_optimizer(opt):
     """Flat-slice optimizer/EMA (3 tensors, fused kernels) and the reference-style per-tensor optimizer/ModelEMA give the same
     weights — for SGD-nesterov and for the AdamW that `optimizer=auto` picks on short runs (trainer.py:778-786)."""
@@ -81,8 +81,12 @@ def test_flat_state_matches_per_tensor_optimizer(opt):
         m = DetectionModel("yolo11n.yaml", nc=80, verbose=False)
         m.load_state_dict(R.seeded_state_dict(R.empty_state_dict(R.resolve_graph("n", nc=80)), seed=4))
         t = DetectionTrainer(m, batch_size=4, device=DEV, overrides={"amp": False, "nbs": 4, **opt}, graphs=False, flat=flat)
-        if opt:
+        if opt.get("optimizer") == "auto":
             assert type(t.optimizer).__name__ == "AdamW" and abs(t.args.lr0 - round(0.002 * 5 / 84, 6)) < 1e-12
+        if opt.get("optimizer") == "Adam":
+            # torch.optim.Adam = L2 decay added to the gradient BEFORE the moments (the reference's build_optimizer, trainer.py:806-807);
+            # the flat step's kind 2 — r03 routed it through the AdamW rule.  A large decay makes the two rules differ visibly.
+            assert type(t.optimizer).__name__ == "Adam" and (not flat or t._opt_kind == 2)
         return t
     ta, tb = mk(True), mk(False)
     for i in range(3):
