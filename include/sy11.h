@@ -79,7 +79,9 @@ int sy11_tune_clear(void);
 int sy11_peak_mfma_f16(int32_t workgroups, int32_t iters, float* out, void* stream);
 /* Diagnostic (tools/igemm8_stamps.py, never on the product path): with SY11_IGEMM_DEBUG=9 the 8-wave convolution pipeline
  * (csrc/igemm8.hip) sums per-section s_memtime deltas in waves 0 / 4 of workgroup 0; this copies the 2 x 8 counters of the
- * last such launch to the HOST array out16 (synchronous).                                                             */
+ * last such launch to the HOST array out16 (synchronous).  With out16[0] == 1 on entry the array must hold 16 + 8 * 2048
+ * elements: the per-workgroup records {entry, exit (100 MHz ticks), XCC id, cycles of the four kernel sections, 0} of the first 2048
+ * workgroups follow.                                                                                                      */
 int sy11_debug_stamps(uint64_t* out16);
 
 /* ---- convolution (replaces nn.Conv2d inside Conv.forward / forward_fuse, nn/modules/conv.py:79-83,

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB, STAGE = A_BYTES + B_BYTES;
   static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
   static_assert(BN % RPP == 0 || BN < RPP, "pass geometry");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE + 192 + 512];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE + 192 + 768];
   __shared__ float s_red[WM * 2 * BN];           // BN batch statistics of this tile, [wave row wm][sum | sumsq][channel]: ordered fold, no LDS atomics
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,14 +115,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   // once; a stage adds one per-tap delta (LDS table) and turns invalid lanes into an out-of-range offset (hardware zero fill).
   const int ld_row = tid / CPRW;
   const int ld_chunk = (tid % CPRW) ^ swz<KB>(ld_row);           // LOGICAL chunk this lane fetches (swizzle is pass-invariant)
-  int* s_tapoff = (int*)(smem + NST * STAGE + 192);              // [64] byte delta of tap t in x, [64] byte delta in w
+  int* s_tapoff = (int*)(smem + NST * STAGE + 192);              // [64] byte delta of tap t in x, [64] byte delta in w, [64] packed (dy, dx)
   if (tid < 64) {
     const int t = tid < a.T ? tid : 0;
-    s_tapoff[tid] = (a.tap_dy[t] * a.IW + a.tap_dx[t]) * a.x_ld * ESZ;
+    const int dy = a.tap_dy[t], dx = a.tap_dx[t];
+    s_tapoff[tid] = (dy * a.IW + dx) * a.x_ld * ESZ;
     s_tapoff[64 + tid] = a.tap_w[t] * a.C * ESZ;
+    s_tapoff[128 + tid] = (dy & 0xffff) | (dx << 16);
   }
   const int ohw = a.OH * a.OW;
-  int a_off[APASS];
+  int a_off[APASS], a_iy[APASS], a_ix[APASS];
   unsigned long long a_mask[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
@@ -132,14 +134,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
     const int b = mm / ohw, r = mm - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
     const int iy0 = oy * a.sy, ix0 = ox * a.sx;
     a_off[i] = ((b * a.IH + iy0) * a.IW + ix0) * a.x_ld * ESZ;       // host guarantees < 2^31 bytes
-    unsigned long long mk = 0;
-    if (ok)
-#pragma unroll 1
-      for (int t = 0; t < a.T; ++t) {
-        const int iy = iy0 + a.tap_dy[t], ix = ix0 + a.tap_dx[t];
-        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) mk |= 1ull << t;
-      }
-    a_mask[i] = mk;
+    a_iy[i] = ok ? iy0 : -0x4000;                                    // a row past M: no tap is inside the image
+    a_ix[i] = ix0;
+    a_mask[i] = 0;
   }
   int b_off[BPASS];
 #pragma unroll
@@ -168,6 +165,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
   const bool chan_major = a.chan_major && a.T > 1 && a.C % BK == 0;
   const bool b_issue = (BN >= RPP) || (wave_u * RPI < BN);         // BN < rows-per-pass: only waves covering real rows issue
   __syncthreads();  // tap tables visible
+  // "tap t of row i lies inside the image", one bit per tap, from the LDS tap table (one broadcast read per tap for all of a lane's rows).
+  // r01-r03 read the taps from the kernel arguments inside this loop: every tap of every row was a dependent scalar-memory round trip,
+  // 16 000 cycles per workgroup on a 3x3 layer (in-kernel stamps of the 8-wave pipeline, r04) — now ~2 000
+#pragma unroll 1
+  for (int t = 0; t < a.T; ++t) {
+    const int v = s_tapoff[128 + t];
+    const int dy = (short)(v & 0xffff), dx = v >> 16;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      if ((unsigned)(a_iy[i] + dy) < (unsigned)a.IH && (unsigned)(a_ix[i] + dx) < (unsigned)a.IW) a_mask[i] |= 1ull << t;
+  }
   {
     const int tt0 = kp.kt < a.T ? kp.kt : 0;
     kp.xo = s_tapoff[tt0];
@@ -515,11 +523,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // 15, 16 = halo-tiled 3x3 kernel (conv3x3.hip) with the widest / the next narrower channel tile
 // 17, 18 = the same with 256-pixel tiles (stride 1): half the filter bytes per FLOP
 // 19 = few-channel 3x3 stride-1 kernel (conv3x3s.hip): C = 16 / 32, N <= 32, the filter resident in registers
-// 20, 21 = 8-wave phase-staggered pipeline (igemm8.hip): 256 pixels x 128 / 64 channels, 128-byte K stages, one workgroup per CU
+// 20, 21 = 8-wave software pipeline (igemm8.hip): 256 pixels x 128 / 64 channels, 128-byte K stages in 3 LDS slots, one workgroup per CU
+// 22, 23 = the same with 64-byte K stages in 6 slots (twice the prefetch distance in cycles)
+// 24 = 256 pixels x 256 channels (wave tile 128 x 64): 64 FLOP per filled byte instead of 43
 constexpr int IGEMM_NCFG = SY11_IGEMM_NCFG;
-static_assert(IGEMM_NCFG == 22, "configuration table and its size (tune.h) out of step");
-bool sy11_igemm8_legal(const IgemmArgs& a, int bn, int epi);
-int sy11_igemm8_launch(const IgemmArgs& a, int bn, int epi, hipStream_t st);
+static_assert(IGEMM_NCFG == 25, "configuration table and its size (tune.h) out of step");
+bool sy11_igemm8_legal(const IgemmArgs& a, int bn, int kb, int epi);
+int sy11_igemm8_launch(const IgemmArgs& a, int bn, int kb, int epi, hipStream_t st);
 static int halo_bn(const IgemmArgs& a, int cfg) {
   const int wide = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   const int bn = (cfg == 15 || cfg == 17) ? wide : (wide > 32 ? wide / 2 : 0);
@@ -540,7 +550,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
     return std::is_same<T, _Float16>::value && bn > 0 && sy11_halo3x3_legal(a, bn);
   }
   if (cfg == 19) return !std::is_same<T, float>::value && sy11_smallc3x3_legal(a);
-  if (cfg == 20 || cfg == 21) return std::is_same<T, _Float16>::value && sy11_igemm8_legal(a, cfg == 20 ? 128 : 64, epi_code(a));
+  if (cfg >= 20 && cfg <= 24) return std::is_same<T, _Float16>::value && sy11_igemm8_legal(a, cfg == 24 ? 256 : ((cfg & 1) ? 64 : 128), cfg < 22 ? 128 : 64, epi_code(a));
   if (cfg == 7 || cfg == 8) {
     const int epi = epi_code(a), bn = cfg == 7 ? 128 : 64;
     if (std::is_same<T, float>::value || a.T != 1 || a.tap_dy[0] || a.tap_dx[0] || a.sy != 1 || a.sx != 1 || !a.dense_out || !a.vec_out) return false;
@@ -568,10 +578,10 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
   if (cfg == 7 || cfg == 8)
     return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
                                  a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st, a.bias);
-  const bool wave8 = cfg == 20 || cfg == 21;
+  const bool wave8 = cfg >= 20 && cfg <= 24;
   const int bm = (cfg == 3 || wave8) ? 256 : 128;
-  const int tile = wave8 ? cfg - 20 : (cfg >= 12 ? cfg - 12 : (cfg >= 9 ? cfg - 9 : (cfg >= 4 ? cfg - 4 : cfg)));
-  const int bn = tile == 1 ? 64 : (tile == 2 ? 32 : 128);
+  const int tile = wave8 ? (cfg & 1) : (cfg >= 12 ? cfg - 12 : (cfg >= 9 ? cfg - 9 : (cfg >= 4 ? cfg - 4 : cfg)));
+  const int bn = cfg == 24 ? 256 : (tile == 1 ? 64 : (tile == 2 ? 32 : 128));
   a.tiles_n = cdiv(a.N, bn);
   const long nwg = (long)cdiv(a.M, bm) * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm: bad grid %ld", nwg);
@@ -614,7 +624,7 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
     }                                                            \
   } while (0)
   if (wave8) {
-    const int rc8 = sy11_igemm8_launch(a, bn, epi_pre, st);
+    const int rc8 = sy11_igemm8_launch(a, bn, cfg < 22 ? 128 : 64, epi_pre, st);
     if (rc8) return rc8;
   } else if (bm == 256) {
     if constexpr (std::is_same<T, _Float16>::value) {
@@ -669,8 +679,8 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
     } else if (sy11tune::enabled() && !sy11tune::capturing(st)) {
       int cands[IGEMM_NCFG], nc = 0;
       for (int c = 0; c < IGEMM_NCFG; ++c) {
-        const int ct = c >= 20 ? c - 20 : (c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c))));
-        const int cbn = ct == 1 ? 64 : (ct == 2 ? 32 : 128);
+        const int ct = c >= 20 ? (c & 1) : (c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c))));
+        const int cbn = c == 24 ? 256 : (ct == 1 ? 64 : (ct == 2 ? 32 : 128));
         if ((c < 15 || c >= 20) && cbn > 32 && cbn >= 2 * a.N) continue;              // tile more than twice the channel count: pure waste
         if (cfg_legal<T>(a, c)) cands[nc++] = c;
       }

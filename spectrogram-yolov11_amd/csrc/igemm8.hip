@@ -1,25 +1,30 @@
-// igemm8.hip — the implicit-GEMM convolution of igemm.hip as an 8-wave, two-waves-per-SIMD, phase-staggered pipeline (r04).
+// igemm8.hip — the implicit-GEMM convolution of igemm.hip as an 8-wave (two waves per SIMD) software pipeline (r04).
 //
 // Why a second main loop.  The 4-wave tiles of igemm.hip run every wave through  barrier -> issue LDS-DMA -> read fragments -> MFMAs:
-// a wave that is issuing its copies is not issuing MFMAs, the workgroups of a CU run in phase, and the r03 counters put the matrix pipe
-// at 50-60 % busy even with the copies compiled out.  Here a workgroup is 512 threads = two wave GROUPS (waves 0-3 / 4-7: wave w and
-// w + 4 share a SIMD).  Group 1 enters the loop one barrier late, and every phase is
-//        L: fragment reads of this phase + this phase's share of the LDS-DMA pieces two stages ahead + (counted) waits
-//        s_barrier
-//        M: 8 x v_mfma_f32_32x32x16 between s_setprio 1 / 0
-//        s_barrier
-// so that while one group sits in M the other sits in L: each SIMD always has one wave feeding the matrix pipe and one wave feeding
-// the address / LDS paths (cdna_hip_programming.md, "The 256^2 8-phase template": same synchronisation skeleton, with this kernel's
-// im2col gather as the copy).  One workgroup per CU (148 KB of LDS), so the stagger is the ONLY overlap and it is deterministic.
+// a wave that is issuing its copies (~65 cycles per 1 KiB piece) is not issuing MFMAs, the workgroups of a CU run in phase, and the
+// matrix pipe sat at 50-60 % busy (r03 counters).  Here a workgroup is 512 threads = two wave GROUPS (waves 0-3 / 4-7: wave w and
+// w + 4 share a SIMD), one workgroup per CU, and a STEP (one 64-deep K stage) is, per wave,
+//        group 1:  [6 pieces of stage s+3]  [16 MFMAs of stage s from registers, interleaved with the 16 fragment reads of stage s+1]
+//        group 0:  [16 MFMAs ... reads ...]  [6 pieces of stage s+3]
+//        both:     counted vmcnt (stage s+2 landed), lgkmcnt(0), ONE s_barrier
+// i.e. the two waves of a SIMD run the same work in opposite order: while one feeds the matrix pipe the other feeds the address path.
+// Fragments are double-buffered in REGISTERS (a whole stage per set), so a stage's LDS slot is free one step early and three slots
+// carry a prefetch distance of three stages.
+//
+// r04 history: the first form followed the guide's 8-phase template literally (two barriers per 8-MFMA phase, group 1 one barrier
+// behind): parity-green and exactly as fast as the 4-wave 256x128 tile (187 vs 186 us on 80x80 256->256 s2).  In-kernel stamps
+// (SY11_IGEMM_DEBUG=9) showed why: per phase the load section (8 reads + 3 pieces + waits) took ~490 cycles against 256 of MFMA, so
+// the computing group waited ~450 cycles at its second barrier — the barriers paced the pipeline at the slower section twice per
+// phase.  This form has one barrier per 512 MFMA cycles and hides the reads under the wave's own MFMAs.
 //
 // Geometry: 256 pixels x BN channels per workgroup (BN = 128: wave tile 64 x 64, or 64: wave tile 64 x 32), stages of 128 BYTES of K
-// per row (64 f16: whole 128-byte lines from HBM / L2), a ring of three stages, two phases (K = 32 each) per stage.
+// per row (64 f16: whole 128-byte lines from HBM / L2), a ring of three LDS slots.
 //
-// Ring discipline (global barrier numbers: group 0 runs L_p between B(2p-1) and B(2p), M_p between B(2p) and B(2p+1); group 1 one later):
-//   RAW  stage s+1 is retired by EVERY wave's own counted s_waitcnt vmcnt in L_{2s+1} (leaving only stage s+2's pieces in flight) and is
-//        first read in L_{2s+2}: at least one barrier after the last wave's wait, for both groups.
-//   WAR  every wave drains its fragment reads (lgkmcnt(0)) BEFORE the barrier that ends its L section, so the last reads of stage s-1
-//        (phase 2s-1) are complete before B(4s-1); its buffer is refilled by pieces issued in L_{2s} / L_{2s+1}, i.e. after B(4s-1).
+// Ring discipline (one barrier B(s) ends step s):
+//   RAW  stage s+2 is retired by EVERY wave's own counted s_waitcnt vmcnt before B(s) (only stage s+3's pieces stay in flight) and is
+//        first read during step s+1.
+//   WAR  stage s+1's fragment reads (issued during step s) are drained by lgkmcnt(0) before B(s); its slot is refilled by the pieces
+//        of stage s+4, issued during step s+1.
 // Each stage is exactly NPC pieces per wave (out-of-range rows are issued as zero-fill pieces), so the counts are exact.
 #include "common.h"
 #include "tune.h"
@@ -46,31 +51,54 @@ __device__ __forceinline__ rsrc8_t make_rsrc(const void* base, unsigned bytes) {
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most min(max(stages, 0), MAXS) x NPC of this wave's pieces are outstanding (wave-uniform `stages`; immediates need a switch)
+template <int NPC, int MAXS> __device__ __forceinline__ void wait_stages(int stages) {
+  static_assert(MAXS <= 5, "wait_stages: switch depth");
+  const int n = stages < 0 ? 0 : (stages > MAXS ? MAXS : stages);
+  if (n == 0) wait_vm<0>();
+  else if (n == 1) wait_vm<NPC>();
+  else if (n == 2) wait_vm<2 * NPC>();
+  else if (n == 3) wait_vm<3 * NPC>();
+  else if (n == 4) wait_vm<4 * NPC>();
+  else wait_vm<5 * NPC>();
+}
+// LDS bank swizzle of a tile row (applied on the SOURCE side of the copies and on the fragment reads): 128-byte rows XOR the 16-byte chunk
+// index with (row >> 1) & 7, 64-byte rows with (row >> 2) & 3 — conflict-free ds_read_b128 fragments (igemm.hip)
+template <int KB> __device__ __forceinline__ int swz8(int r) { return KB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
 // diagnostic build only (SY11_IGEMM_DEBUG=9): where a phase spends its cycles.  Wave 0 and wave 4 of workgroup 0 add up, over all
-// phases, the s_memtime deltas of [fragment-read issue | piece issue | counted waits | barrier 1 | MFMA issue | barrier 2] + the phase
+// steps, the s_memtime deltas of [group 1's piece issue | MFMAs + fragment reads | group 0's piece issue + counted waits | barrier] + the step
 // count + the whole kernel; read back with sy11_debug_stamps().  Nothing else in the kernel reads this memory.
 __device__ unsigned long long g_i8_stamp[2][8];
+__device__ unsigned long long g_i8_wg[2048][8];     // per workgroup (first 2048): entry / exit in s_memrealtime ticks (100 MHz), XCC id, then shader cycles entry -> addresses set up -> first step -> last step done -> epilogue done
 __device__ __forceinline__ unsigned long long stamp() { return __builtin_amdgcn_s_memtime(); }
 
 }  // namespace
 
-// EPI bits as in igemm.hip: 1 statistics, 2 bias, 4 SiLU, 8 accumulate.  Instantiated: 0, 1, 8, 6.
-template <int BN, int EPI>
+// EPI bits as in igemm.hip: 1 statistics, 2 bias, 4 SiLU, 8 accumulate.  Instantiated: 0, 1, 8, 6.  DBG = 1: the diagnostic build (honours
+// SY11_IGEMM_DEBUG 2 = no MFMAs and 9 = cycle stamps; instantiated for <128, 1> only) — the product build carries none of those branches.
+template <int BN, int KB, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
   typedef _Float16 T;
-  constexpr int BM = 256, KB = 128, ESZ = 2, EPC = 8, CPRW = 8, BK = 64, NST = 3;
-  constexpr int RPI = 8, RPP = 64;                   // rows per wave-instruction, rows per pass of the 8 waves
+  constexpr int BM = 256, ESZ = 2, EPC = 8, BK = KB / ESZ;
+  constexpr bool ROLL = BN == 256;                   // 256 x 256 tile: k-group-granular register double buffering (see the main loop)
+  constexpr int NST = ROLL ? 4 : (KB == 128 ? 3 : 6);   // LDS slots: 3 x 48 KB / 6 x 24 KB (BN = 128), 4 x 32 KB (BN = 256)
+  static_assert(!ROLL || KB == 64, "the 256-channel tile takes 64-byte stages");
+  constexpr int CPRW = KB / 16, G = KB / 32;         // 16-byte chunks per row; k-groups (16 k = one MFMA) per stage
+  constexpr int RPI = 64 / CPRW, RPP = 8 * RPI;      // rows per wave-instruction, rows per pass of the 8 waves
   constexpr int APASS = BM / RPP, BPASS = BN / RPP;
-  constexpr int MI = 2, NI = BN / 64;                // 32 x 32 blocks of a wave tile (64 rows x BN / 2 columns)
+  static_assert(BPASS >= 1, "a pass of the 8 waves must not cover more filter rows than the tile has");
+  constexpr int MI = ROLL ? 4 : 2, NI = ROLL ? 2 : BN / 64;   // 32 x 32 blocks of a wave tile: 64 rows x BN / 2 columns, or 128 x 64 (BN = 256)
+  constexpr int RG = ROLL ? 2 : 4;                   // wave rows of the tile (statistics fold)
   constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB, STAGE = A_BYTES + B_BYTES;
   constexpr int NPC = APASS + BPASS;                 // LDS-DMA pieces per wave and stage
-  constexpr int A_H0 = APASS / 2, B_H0 = (BPASS + 1) / 2;   // passes issued in phase 0 of a stage (the rest in phase 1)
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int TAB = NST * STAGE;                   // tap tables: [64] x delta, [64] w delta
-  constexpr int RED = TAB + 512;                     // statistics fold: [4 row groups][sum | sumsq][BN]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RED + 4 * 2 * BN * 4];
+  constexpr int TAB = NST * STAGE;                   // tap tables: [64] x delta, [64] w delta, [64] packed (dy, dx)
+  constexpr int RED = TAB + 768;                     // statistics fold: [RG wave rows][sum | sumsq][BN]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RED + RG * 2 * BN * 4];
 
+  const unsigned long long t_entry = (DBG && a.debug == 9) ? stamp() : 0;
+  const unsigned long long r_begin = (DBG && a.debug == 9) ? __builtin_amdgcn_s_memrealtime() : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wm2 = (wave >> 1) & 1, wn = wave & 1;
@@ -84,16 +112,18 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
   // ---- copy side: lane -> (row within a pass, 16-byte chunk); the bank swizzle sits on the SOURCE side
-  const int ld_row = tid >> 3;
-  const int ld_chunk = (tid & 7) ^ ((ld_row >> 1) & 7);
+  const int ld_row = tid / CPRW;
+  const int ld_chunk = (tid % CPRW) ^ swz8<KB>(ld_row);
   int* s_tapoff = (int*)(smem + TAB);
   if (tid < 64) {
     const int t = tid < a.T ? tid : 0;
-    s_tapoff[tid] = (a.tap_dy[t] * a.IW + a.tap_dx[t]) * a.x_ld * ESZ;
+    const int dy = a.tap_dy[t], dx = a.tap_dx[t];
+    s_tapoff[tid] = (dy * a.IW + dx) * a.x_ld * ESZ;
     s_tapoff[64 + tid] = a.tap_w[t] * a.C * ESZ;
+    s_tapoff[128 + tid] = (dy & 0xffff) | (dx << 16);
   }
   const int ohw = a.OH * a.OW;
-  int a_off[APASS];
+  int a_off[APASS], a_iy[APASS], a_ix[APASS];
   unsigned long long a_mask[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
@@ -103,14 +133,9 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
     const int b = mm / ohw, r = mm - b * ohw, oy = r / a.OW, ox = r - oy * a.OW;
     const int iy0 = oy * a.sy, ix0 = ox * a.sx;
     a_off[i] = ((b * a.IH + iy0) * a.IW + ix0) * a.x_ld * ESZ;
-    unsigned long long mk = 0;
-    if (ok)
-#pragma unroll 1
-      for (int t = 0; t < a.T; ++t) {
-        const int iy = iy0 + a.tap_dy[t], ix = ix0 + a.tap_dx[t];
-        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) mk |= 1ull << t;
-      }
-    a_mask[i] = mk;
+    a_iy[i] = ok ? iy0 : -0x4000;                    // a row past M: no tap is inside the image
+    a_ix[i] = ix0;
+    a_mask[i] = 0;
   }
   int b_off[BPASS];
 #pragma unroll
@@ -127,6 +152,18 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
   const bool simple_k = a.C >= BK;
   const bool chan_major = a.chan_major && a.T > 1 && a.C % BK == 0;
   __syncthreads();                                   // tap tables visible
+  // "tap t of row i lies inside the image", one bit per tap.  The taps come from the LDS table (one broadcast read per tap for all of
+  // a lane's rows): read from the kernel arguments inside this loop (r03 form, still in igemm.hip's 4-wave tiles until r04) every tap of
+  // every row was a dependent scalar-memory round trip — 16 000 cycles per workgroup on a 3x3 layer, a quarter of a K = 1152 tile's life
+  // (in-kernel stamps, tools/igemm8_stamps.py).
+#pragma unroll 1
+  for (int t = 0; t < a.T; ++t) {
+    const int v = s_tapoff[128 + t];
+    const int dy = (short)(v & 0xffff), dx = v >> 16;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      if ((unsigned)(a_iy[i] + dy) < (unsigned)a.IH && (unsigned)(a_ix[i] + dx) < (unsigned)a.IW) a_mask[i] |= 1ull << t;
+  }
   {
     const int tt0 = kp.kt < a.T ? kp.kt : 0;
     kp.xo = s_tapoff[tt0];
@@ -134,24 +171,20 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
   }
   const unsigned piece0 = smem_base + wave * (RPI * KB);
 
-  // half H of the pieces of one stage into ring slot `slot`, at K position k
-  auto issue_half = [&](int slot, int half, const KPos& k) {
+  // the NPC pieces of one stage into ring slot `slot`, at K position k
+  auto issue_stage = [&](int slot, const KPos& k) {
     const unsigned sa = piece0 + slot * STAGE, sb = sa + A_BYTES;
     const bool kvalid = k.kt < a.T;
     const int tt = kvalid ? k.kt : 0;
     const int xo = k.xo + k.kc * ESZ, wo = k.wo + k.kc * ESZ;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      if ((i < A_H0) != (half == 0)) continue;
       const bool ok = kvalid && ((a_mask[i] >> tt) & 1ull);
-      if (a.debug == 6) continue;                    // ablation: no pixel-row pieces
       dma16(sa + i * (RPP * KB), ok ? (unsigned)(a_off[i] + xo) : OOB, xr);
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-      if ((i < B_H0) != (half == 0)) continue;
       const unsigned off = (kvalid && b_off[i] >= 0) ? (unsigned)(b_off[i] + wo) : OOB;
-      if (a.debug == 7) continue;                    // ablation: no filter-row pieces
       dma16(sb + i * (RPP * KB), off, wr);
     }
   };
@@ -188,92 +221,161 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int frow = lane & 31, fh = lane >> 5;
-  const int wrow0 = grp * 128 + wm2 * 64, wcol0 = wn * (BN / 2);
+  const int wrow0 = ROLL ? grp * 128 : grp * 128 + wm2 * 64, wcol0 = ROLL ? (wave & 3) * 64 : wn * (BN / 2);
   // fragment byte offsets inside a stage for k-group g (16 k = two 16-byte chunks: lane half fh owns chunk 2g + fh); rows r and r + 32
   // share the swizzle, so block i / j adds a compile-time 32 * KB
-  int fa_off[4], fb_off[4];
+  int fa_off[G], fb_off[G];
   {
     const int ra = wrow0 + frow, rb = wcol0 + frow;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      fa_off[g] = ra * KB + (((2 * g + fh) ^ ((ra >> 1) & 7)) << 4);
-      fb_off[g] = A_BYTES + rb * KB + (((2 * g + fh) ^ ((rb >> 1) & 7)) << 4);
+    for (int g = 0; g < G; ++g) {
+      fa_off[g] = ra * KB + (((2 * g + fh) ^ swz8<KB>(ra)) << 4);
+      fb_off[g] = A_BYTES + rb * KB + (((2 * g + fh) ^ swz8<KB>(rb)) << 4);
     }
   }
   const int nstage = (a.K + BK - 1) / BK;
-  const bool timing = a.debug == 9 && blockIdx.x == 0 && (wave & 3) == 0;
+  const bool timing = DBG && a.debug == 9 && blockIdx.x == 0 && (wave & 3) == 0;
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long t_begin = timing ? stamp() : 0;
+  const unsigned long long t_begin = (DBG && a.debug == 9) ? stamp() : 0;
+  unsigned long long t_loop = 0;
 
-  // ---- prologue: stages 0 and 1 in flight, stage 0 landed and visible
-  issue_half(0, 0, kp);
-  issue_half(0, 1, kp);
-  kp = advance(kp);
-  if (nstage > 1) {
-    issue_half(1, 0, kp);
-    issue_half(1, 1, kp);
-    kp = advance(kp);
-    wait_vm<NPC>();
-  } else {
-    wait_vm<0>();
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();        // the stagger: group 1 runs one barrier behind group 0
-
-  for (int s0 = 0; s0 < nstage; s0 += NST) {
+  if constexpr (ROLL) {
+    // ---- 256 x 256 tile: 128 accumulator registers leave room for TWO k-groups of fragments (2 x 24 registers), not two stages: the
+    // reads of k-group g + 1 (the next stage's k-group 0 behind the last one) run under the 8 MFMAs of k-group g.  A slot is then read
+    // during its own step (and its k-group 0 during the step before), so it is free one step LATER than in the whole-stage scheme:
+    // four slots = stage s (being read), s + 1 (k-group 0 being read), s + 2 (landed by the end of the step), s + 3 (in flight, in the slot
+    // stage s - 1 left).   RAW: stage s + 2 retired before B(s), first read (k-group 0) during step s + 1.   WAR: slot of stage s - 1:
+    // last read during step s - 1, drained before B(s - 1); refilled by pieces issued during step s.
+    static_assert(G == 2, "rolling scheme: two k-groups per stage");
+    const int npro = nstage < NST - 1 ? nstage : NST - 1;
 #pragma unroll
-    for (int u = 0; u < NST; ++u) {
-      const int s = s0 + u;
-      if (s < nstage) {
-        const unsigned char* st = smem + u * STAGE;
-        const bool more = s + 2 < nstage && a.debug != 1;
+    for (int q = 0; q < NST - 1; ++q)
+      if (q < nstage) { issue_stage(q, kp); kp = advance(kp); }
+    wait_stages<NPC, NST - 2>(npro - 1);               // stage 0 has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    uint4 rA[2][MI], rB[2][NI];                        // [register set = k-group parity][32-row block]
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-          if (timing) c0 = stamp();
-          // ---- L: this phase's fragments (k-groups 2h, 2h + 1), then the pieces of stage s + 2
-          uint4 fa[2][MI], fb[2][NI];
-          if (a.debug != 8)                          // ablation 8: copies and barriers only
+    for (int i = 0; i < MI; ++i) rA[0][i] = *(const uint4*)(smem + fa_off[0] + i * (32 * KB));
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {
+    for (int j = 0; j < NI; ++j) rB[0][j] = *(const uint4*)(smem + fb_off[0] + j * (32 * KB));
+    wait_stages<NPC, NST - 2>(npro - 2);               // stage 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (DBG) t_loop = stamp();
+    for (int s0 = 0; s0 < nstage; s0 += NST) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[g][i] = *(const uint4*)(st + fa_off[2 * h + g] + i * (32 * KB));
-#pragma unroll
-            for (int j = 0; j < NI; ++j) fb[g][j] = *(const uint4*)(st + fb_off[2 * h + g] + j * (32 * KB));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (timing) c1 = stamp();
-          if (more) issue_half((u + 2) % NST, h, kp);
-          if (timing) c2 = stamp();
-          if (h == 1) {
-            if (more) { kp = advance(kp); wait_vm<NPC>(); }      // stage s + 1 has landed (this wave's pieces); stage s + 2 stays in flight
-            else wait_vm<0>();
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // fragments in registers BEFORE the barrier: the slot may be refilled after it
-          __builtin_amdgcn_sched_barrier(0);
-          if (timing) c3 = stamp();
-          __builtin_amdgcn_s_barrier();
-          if (timing) c4 = stamp();
-          // ---- M
+      for (int u = 0; u < NST; ++u) {
+        const int s = s0 + u;
+        if (s < nstage) {
+          const unsigned char* cu = smem + u * STAGE;                 // stage s (its k-group 1)
+          const unsigned char* nx = smem + ((u + 1) % NST) * STAGE;   // stage s + 1 (its k-group 0)
+          const bool more = s + NST - 1 < nstage && a.debug != 1;     // stage s + 3 goes into the slot stage s - 1 has left
+          if (grp == 1 && more) issue_stage((u + NST - 1) % NST, kp);
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_setprio(1);
-          if (a.debug != 2 && a.debug != 8) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+          for (int g = 0; g < G; ++g) {
+            const unsigned char* src = g + 1 < G ? cu : nx;
+            const int gn = g + 1 < G ? g + 1 : 0;
 #pragma unroll
-              for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) rA[gn & 1][i] = *(const uint4*)(src + fa_off[gn] + i * (32 * KB));
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[g][i]), __builtin_bit_cast(f16x8, fb[g][j]), acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j) rB[gn & 1][j] = *(const uint4*)(src + fb_off[gn] + j * (32 * KB));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rA[g & 1][i]), __builtin_bit_cast(f16x8, rB[g & 1][j]), acc[i][j], 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < G * MI * NI; ++q) {      // one fragment read per MFMA gap; k-group g's MFMAs wait only for k-group g's reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q % (MI * NI) < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
-          if (timing) c5 = stamp();
+          if (grp == 0 && more) issue_stage((u + NST - 1) % NST, kp);
+          if (more) kp = advance(kp);
+          wait_stages<NPC, 1>(a.debug == 1 ? 0 : nstage - 3 - s);     // stage s + 2 has landed; stage s + 3 stays in flight
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+    }
+  } else {
+    // ---- prologue: stages 0 .. NST-1 in flight; stage 0's fragments in register set 0; stage 1 landed and visible
+    const int npro = nstage < NST ? nstage : NST;
+  #pragma unroll
+    for (int q = 0; q < NST; ++q)
+      if (q < nstage) { issue_stage(q, kp); kp = advance(kp); }
+    wait_stages<NPC, NST - 1>(npro - 1);               // stage 0 has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                      // ... and is visible to every wave
+    uint4 fA[2][G][MI], fB[2][G][NI];                  // [register set][k-group][32-row block]
+  #pragma unroll
+    for (int g = 0; g < G; ++g) {
+  #pragma unroll
+      for (int i = 0; i < MI; ++i) fA[0][g][i] = *(const uint4*)(smem + fa_off[g] + i * (32 * KB));
+  #pragma unroll
+      for (int j = 0; j < NI; ++j) fB[0][g][j] = *(const uint4*)(smem + fb_off[g] + j * (32 * KB));
+    }
+    wait_stages<NPC, NST - 1>(npro - 2);               // stage 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // stage 1 visible; slot 0 free (its fragments are in registers)
+
+    if (DBG) t_loop = stamp();
+    for (int s0 = 0; s0 < nstage; s0 += 2 * NST) {
+  #pragma unroll
+      for (int u = 0; u < 2 * NST; ++u) {
+        const int s = s0 + u;
+        if (s < nstage) {
+          const int cur = u & 1, nxt = cur ^ 1;                      // compile-time after unrolling (2 * NST is even and a multiple of NST)
+          const unsigned char* nx = smem + ((u + 1) % NST) * STAGE;  // stage s + 1: read into the other register set during this step's MFMAs
+          const bool more = s + NST < nstage && a.debug != 1;        // stage s + NST goes into the slot stage s has just left
+          unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+          if (timing) c0 = stamp();
+          if (grp == 1 && more) issue_stage(u % NST, kp);
+          if (timing) c1 = stamp();
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef I8_NO_PRIO
+          __builtin_amdgcn_s_setprio(1);
+#endif
+  #pragma unroll
+          for (int g = 0; g < G; ++g) {
+  #pragma unroll
+            for (int i = 0; i < MI; ++i) fA[nxt][g][i] = *(const uint4*)(nx + fa_off[g] + i * (32 * KB));
+  #pragma unroll
+            for (int j = 0; j < NI; ++j) fB[nxt][g][j] = *(const uint4*)(nx + fb_off[g] + j * (32 * KB));
+            if (!DBG || a.debug != 2) {
+  #pragma unroll
+              for (int i = 0; i < MI; ++i)
+  #pragma unroll
+                for (int j = 0; j < NI; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fA[cur][g][i]), __builtin_bit_cast(f16x8, fB[cur][g][j]), acc[i][j], 0, 0, 0);
+            }
+          }
+          // one fragment read per MFMA gap (left alone the compiler issues all the reads in a row behind the first MFMA: ~100 idle pipe cycles)
+#ifndef I8_NO_INTERLEAVE
+  #pragma unroll
+          for (int q = 0; q < G * MI * NI; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < G * (MI + NI)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+#endif
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (timing) c2 = stamp();
+          if (grp == 0 && more) issue_stage(u % NST, kp);
+          if (more) kp = advance(kp);
+          // stage s + 2 has landed (this wave's pieces); the stages issued after it — up to NST - 2 of them — stay in flight
+          wait_stages<NPC, NST - 2>(a.debug == 1 ? 0 : nstage - 3 - s);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // stage s + 1 is in registers: its slot may be refilled after the barrier
+          __builtin_amdgcn_sched_barrier(0);
+          if (timing) c3 = stamp();
           __builtin_amdgcn_s_barrier();
           if (timing) {
-            const unsigned long long c6 = stamp();
-            tacc[0] += c1 - c0; tacc[1] += c2 - c1; tacc[2] += c3 - c2; tacc[3] += c4 - c3; tacc[4] += c5 - c4; tacc[5] += c6 - c5; tacc[6] += 1;
+            const unsigned long long c4 = stamp();
+            tacc[0] += c1 - c0; tacc[1] += c2 - c1; tacc[2] += c3 - c2; tacc[3] += c4 - c3; tacc[6] += 1;
           }
         }
       }
@@ -284,7 +386,14 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
     for (int q = 0; q < 7; ++q) g_i8_stamp[grp][q] = tacc[q];
     g_i8_stamp[grp][7] = stamp() - t_begin;
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the stagger
+  if (DBG && a.debug == 9 && tid == 0 && blockIdx.x < 2048) {
+    g_i8_wg[blockIdx.x][0] = r_begin;
+    g_i8_wg[blockIdx.x][2] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);       // HW_REG_XCC_ID (id 20), bits 3:0
+    g_i8_wg[blockIdx.x][3] = t_begin - t_entry;
+    g_i8_wg[blockIdx.x][4] = t_loop - t_begin;
+    g_i8_wg[blockIdx.x][5] = stamp() - t_loop;
+  }
+  const unsigned long long t_epi = (DBG && a.debug == 9) ? stamp() : 0;
   __syncthreads();                                   // every fragment read done: the ring becomes the output staging tile
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -352,7 +461,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
   }
   if (EPI & 1) {
     float* s_red = (float*)(smem + RED);
-    const int rg = grp * 2 + wm2;
+    const int rg = ROLL ? grp : grp * 2 + wm2;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const float s1 = ssum[j] + __shfl_xor(ssum[j], 32);
@@ -368,35 +477,48 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const IgemmArgs a) {
       const long so = (long)(blockIdx.x % a.stat_slots) * a.stat_stride;
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { t1 += s_red[r * 2 * BN + tid]; t2 += s_red[r * 2 * BN + BN + tid]; }
+      for (int r = 0; r < RG; ++r) { t1 += s_red[r * 2 * BN + tid]; t2 += s_red[r * 2 * BN + BN + tid]; }
       atomicAdd(a.stat_sum + so + bn0 + tid, t1);
       atomicAdd(a.stat_sq + so + bn0 + tid, t2);
     }
   }
+  if (DBG && a.debug == 9 && tid == 0 && blockIdx.x < 2048) {
+    g_i8_wg[blockIdx.x][6] = stamp() - t_epi;
+    g_i8_wg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
-// f16 only, 16-byte addressable output rows, epilogues 0 / 1 / 8 / 6, no BN tail ticket; bn = 128 or 64
-bool sy11_igemm8_legal(const IgemmArgs& a, int bn, int epi) {
-  if (bn != 128 && bn != 64) return false;
+// f16 only, 16-byte addressable output rows, epilogues 0 / 1 / 8 / 6, no BN tail ticket; bn = 256, 128 or 64; kb = 128 or 64 bytes of K per stage
+bool sy11_igemm8_legal(const IgemmArgs& a, int bn, int kb, int epi) {
+  if (bn != 256 && bn != 128 && bn != 64) return false;
+  if (kb != 128 && kb != 64) return false;
+  if (bn == 64 && kb == 64) return false;           // a pass of the 8 waves would cover 128 filter rows: not instantiated
+  if (bn == 256 && kb != 64) return false;          // 256 x 256: 64-byte stages in four slots
   if (epi != 0 && epi != 1 && epi != 8 && epi != 6) return false;
   if (!a.vec_out || a.tail.ticket || a.M < 256 || a.K < 128) return false;
   if (a.C % 8) return false;                         // a 16-byte chunk never straddles two taps
-  return bn == 128 ? a.N > 64 : (a.N > 32 && a.N <= 64);
+  return bn == 256 ? a.N > 128 : (bn == 128 ? a.N > 64 : (a.N > 32 && a.N <= 64));
 }
 
-int sy11_igemm8_launch(const IgemmArgs& a, int bn, int epi, hipStream_t st) {
+int sy11_igemm8_launch(const IgemmArgs& a, int bn, int kb, int epi, hipStream_t st) {
   const long nwg = (long)cdiv(a.M, 256) * cdiv(a.N, bn);
   if (nwg <= 0 || nwg > 0x7fffffffL) SY11_FAIL(SY11_EINVAL, "igemm8: bad grid %ld", nwg);
   dim3 grid((unsigned)nwg), block(512);
-#define SY11_I8(BNN)                                                                                   \
-  do {                                                                                                 \
-    if (epi == 0) hipLaunchKernelGGL((igemm8_kernel<BNN, 0>), grid, block, 0, st, a);                  \
-    else if (epi == 1) hipLaunchKernelGGL((igemm8_kernel<BNN, 1>), grid, block, 0, st, a);             \
-    else if (epi == 8) hipLaunchKernelGGL((igemm8_kernel<BNN, 8>), grid, block, 0, st, a);             \
-    else hipLaunchKernelGGL((igemm8_kernel<BNN, 6>), grid, block, 0, st, a);                           \
+#define SY11_I8(BNN, KBB)                                                                                  \
+  do {                                                                                                     \
+    if (epi == 0) hipLaunchKernelGGL((igemm8_kernel<BNN, KBB, 0>), grid, block, 0, st, a);                 \
+    else if (epi == 1) hipLaunchKernelGGL((igemm8_kernel<BNN, KBB, 1>), grid, block, 0, st, a);            \
+    else if (epi == 8) hipLaunchKernelGGL((igemm8_kernel<BNN, KBB, 8>), grid, block, 0, st, a);            \
+    else hipLaunchKernelGGL((igemm8_kernel<BNN, KBB, 6>), grid, block, 0, st, a);                          \
   } while (0)
-  if (bn == 128) SY11_I8(128);
-  else SY11_I8(64);
+  if (bn == 128 && epi == 1 && (a.debug == 2 || a.debug == 9)) {
+    if (kb == 128) hipLaunchKernelGGL((igemm8_kernel<128, 128, 1, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((igemm8_kernel<128, 64, 1, 1>), grid, block, 0, st, a);
+  } else if (bn == 256) SY11_I8(256, 64);
+  else if (bn == 128 && kb == 128) SY11_I8(128, 128);
+  else if (bn == 128) SY11_I8(128, 64);
+  else if (kb == 128) SY11_I8(64, 128);
+  else SY11_FAIL(SY11_EINVAL, "igemm8: 64-channel tiles take 128-byte stages only");
 #undef SY11_I8
   SY11_LAUNCH_CHECK("igemm8");
   return SY11_OK;
@@ -405,6 +527,12 @@ int sy11_igemm8_launch(const IgemmArgs& a, int bn, int epi, hipStream_t st) {
 // diagnostic: the 16 counters of the last SY11_IGEMM_DEBUG=9 launch ([wave group][6 section sums | phases | kernel cycles])
 extern "C" int sy11_debug_stamps(uint64_t* out16) {
   SY11_REQUIRE(out16 != nullptr, "debug_stamps: null pointer");
+  // out16[16 ...]: callers that pass a (16 + 4 * 2048)-element array and set out16[0] = 1 also get the per-workgroup records
+  const bool want_wg = out16[0] == 1;
+  if (want_wg && hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(g_i8_wg), sizeof(unsigned long long) * 8 * 2048) != hipSuccess) {
+    (void)hipGetLastError();
+    SY11_FAIL(SY11_ELAUNCH, "debug_stamps: copy failed");
+  }
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_i8_stamp), sizeof(unsigned long long) * 16) != hipSuccess) {
     (void)hipGetLastError();
     SY11_FAIL(SY11_ELAUNCH, "debug_stamps: copy failed");
