@@ -19,3 +19,14 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 print(f"producer: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per 64-image batch")
+db, mm = p.logmel_db(iq)
+torch.cuda.synchronize()
+for what, fn in (("stft_logmel alone", lambda: p.logmel_db(iq)),):
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    by = 64 * p.n_samples * 8 + 64 * 640 * 640 * 4                      # every IQ sample once + every dB value once
+    print(f"{what}: {us:.1f} us = {by / us / 1e3:.0f} GB/s algorithmic ({by / 1e6:.0f} MB)")
