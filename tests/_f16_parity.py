@@ -23,26 +23,18 @@ The criterion is split the way the reference splits it (utils/loss.py:250-258: t
   3. how many anchors the oracle's OWN logits (16-bit emulation) would have assigned differently is measured and printed: that is
      the whole effect the r02 retry was hiding (r02 log: one pre-trained state in twelve had the whole gradient 3.4 % apart).
 
-Why the model state is "default initialisation + a few hundred f32 SGD steps on the device": at initialisation every anchor
-predicts the same box / class logits (Detect.bias_init); a trained state is simply a more realistic input.
-
-Bars (north_star / VERDICT r02 #1): loss within 2e-3; whole-gradient relative error within 1e-2, per-tensor median within 1e-2,
-every tensor within 5 % of its norm (+ an absolute floor, see below: filters in front of a BatchNorm and biases feeding one have
-an exactly-zero true gradient, what is measured there is 16-bit rounding noise on both sides).
-
-The emulation is ONE realisation of the 16-bit rounding, not the truth, and for some model states it is itself noisier than those
-bars: the max-pools of SPPF route a gradient to whichever of two near-equal 16-bit activations wins, so the filters around model.9
-can sit 5-13 % apart between two runs of the ORACLE that differ only in the order of the batch.  The model state comes out of
-device f32 training, so any change of a kernel's summation order gives this test a different instance (r03: per-tensor worsts of
-3.5 %, 5.5 % and 13 % from three builds; with atomic-mode training, whole-gradient distances of 1.7e-3 ... 1.6e-2 and twice
-7e-2 over 18 states).  Two more oracle runs therefore calibrate every instance: (2b) the emulation with the batch reordered —
-its own noise — and (2c) the plain f32 oracle — the truth both 16-bit computations approximate.  A tensor (or the whole
-gradient) beyond the fixed bar passes only if the device is within twice the emulation's reorder noise there, or no farther
-from the f32 gradient than 1.5x the emulation is (tools/f16_state_probe.py: over 8 states the device's 16-bit error was 0.2-1.1x
-the emulation's; tools/atomic_mode_probe.py: atomic and ordered mode differ by 1e-6 in f32, so there is no race behind the
-spread).  Every such tensor is printed with all four distances.
-With ordered reductions
-(tests/conftest.py) the device result is reproducible bit for bit, so none of these bars carries a run-to-run allowance any more."""
+The model state is "default initialisation + a few dozen f32 SGD steps of the CPU ORACLE trainer" (``pretrained_state``): at
+initialisation every anchor predicts the same box / class logits (Detect.bias_init); a trained state is simply a more realistic
+input.  r03 trained the state with the DEVICE's own f32 kernels, so any change of a kernel's summation order handed this test
+a different instance (per-tensor worsts of 3.5 %, 5.5 % and 13 % from three builds), and it let a tensor beyond its bar pass when
+the device was within twice the emulation's reorder noise or no farther from the f32 gradient than 1.5x the emulation.  r04
+(VERDICT r03 #6): the instance is FIXED — produced on the CPU by oracle/train_ref.py from a seed, nothing under test takes part —
+and so are the bars: loss within 2e-3; whole gradient within 2e-2 of the f32 oracle gradient and within 3e-2 of the emulation
+(cosine >= 0.9995; why both, see the assertion); per-tensor median within 1e-2; EVERY tensor within 5 % of its norm plus an absolute floor (filters in front of a BatchNorm and biases feeding one have an
+exactly-zero true gradient: what is measured there is 16-bit rounding noise on both sides).  The emulation with the batch
+reordered (2b: its own noise) and the plain f32 oracle (2c: the truth both 16-bit computations approximate) are still run, as
+PRINTED DIAGNOSTICS for whoever has to explain a failure — they no longer decide anything.
+With ordered reductions (tests/conftest.py) the device result is reproducible bit for bit, so no bar carries a run-to-run allowance."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -55,20 +47,34 @@ GAINS = (7.5, 0.5, 1.5)
 STRIDES = (8.0, 16.0, 32.0)
 
 
-def pretrained_state(cfg, nc, nb, sz, steps, seed=11):
-    from sy11.engine.trainer import DetectionTrainer
+def pretrained_state(cfg, layers, nc, nb, sz, steps, seed=11):
+    """The model state under test: the constructor's initialisation (torch seed ``seed``) after ``steps`` SGD steps of the CPU ORACLE
+    trainer (oracle/train_ref.py: f32, autograd backward, the reference's update rule) on seeded random images / boxes.
+    r03 trained this state with the DEVICE's f32 kernels, so any change of a kernel's summation order handed the test a different
+    instance (VERDICT r03, weak #1); the CPU trainer depends on nothing under test.  Cached per session (a few tens of seconds)."""
+    import hashlib
+    import os
+    import tempfile
+    from oracle import train_ref as TR
     from sy11.nn.tasks import DetectionModel
+    tag = hashlib.sha1(repr((cfg, nc, nb, sz, steps, seed, torch.__version__)).encode()).hexdigest()[:16]
+    path = os.path.join(tempfile.gettempdir(), f"sy11_f16_parity_state_{tag}.pt")
+    if os.path.exists(path):
+        return torch.load(path)
     torch.manual_seed(seed)
     m0 = DetectionModel(cfg, ch=3, nc=nc, verbose=False)
-    tr = DetectionTrainer(m0, batch_size=nb, device=DEV, overrides={"amp": False, "nbs": nb, "warmup_epochs": 0}, graphs=False)
+    sd0 = {k: v.detach().clone() for k, v in m0.state_dict().items()}
     g = torch.Generator().manual_seed(seed)
-    for _ in range(steps):
-        n = 3 * nb
-        b = {"img": torch.rand(nb, 3, sz, sz, generator=g).to(DEV), "batch_idx": torch.arange(nb).repeat_interleave(3).float().to(DEV),
-             "cls": torch.randint(0, nc, (n, 1), generator=g).float().to(DEV),
-             "bboxes": torch.cat((0.25 + 0.5 * torch.rand(n, 2, generator=g), 0.1 + 0.4 * torch.rand(n, 2, generator=g)), 1).to(DEV)}
-        tr.train_step(b)
-    return {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    n_img = nb * 8                                                      # eight distinct mini-batches, taken in order, wrapping
+    imgs = torch.rand(n_img, 3, sz, sz, generator=g)
+    n = 3 * n_img
+    labels = (torch.arange(n_img).repeat_interleave(3).float(), torch.randint(0, nc, (n, 1), generator=g).float(),
+              torch.cat((0.25 + 0.5 * torch.rand(n, 2, generator=g), 0.1 + 0.4 * torch.rand(n, 2, generator=g)), 1))
+    st, losses = TR.train(sd0, layers, nc, imgs, labels, nb, steps)
+    print(f"f16 parity {cfg}: CPU oracle pre-training, {steps} steps: loss {losses[0]:.1f} -> {losses[-1]:.1f}")
+    sd = {k: v.detach().clone() for k, v in st.sd.items()}
+    torch.save(sd, path)
+    return sd
 
 
 def oracle_assignment(maps_nchw, batch, nc):
@@ -114,9 +120,9 @@ def pinned_device_step(m, batch, nc, loss_scale, pin=None):
     return loss.item(), grads, [f.detach().float().cpu() for f in maps], dev_assign.cpu(), [d.permute(0, 3, 1, 2).float().cpu() for d in dmaps]
 
 
-def run_f16_parity(cfg, layers, nc, nb=16, sz=256, steps=200, loss_scale=64.0, seed=11):
+def run_f16_parity(cfg, layers, nc, nb=16, sz=256, steps=40, loss_scale=64.0, seed=11, pre_nb=8, pre_sz=160):
     from sy11.nn.tasks import DetectionModel
-    sd = pretrained_state(cfg, nc, nb, sz, steps, seed=seed)
+    sd = pretrained_state(cfg, layers, nc, pre_nb, pre_sz, steps, seed=seed)       # (the CPU trainer's batch: small, it only has to leave the initialisation)
     g = torch.Generator().manual_seed(3)
     img = torch.rand(nb, 3, sz, sz, generator=g)
     n = 2 * nb
@@ -204,11 +210,15 @@ def run_f16_parity(cfg, layers, nc, nb=16, sz=256, steps=200, loss_scale=64.0, s
     ft = torch.cat([tg32[k].flatten() for k in keys])
     e_dev, e_orc = (fa - ft).norm().item() / ft.norm().item(), (fb - ft).norm().item() / ft.norm().item()
     print(f"f16 parity {cfg}: distance from the f32 oracle gradient: device f16 {e_dev:.3e}, emulating oracle {e_orc:.3e}")
+    # FIXED bars on a FIXED instance (r04): the distances to the reordered emulation (2b) and to the f32 oracle (2c) are
+    # printed diagnostics, no longer alternative ways to pass
+    # Whole gradient: within 2e-2 of the f32 ORACLE gradient — the truth — and within 3e-2 of the emulation.  Why not "1e-2 of the emulation":
+    # on the fusion variant the emulation ITSELF sits 2.6e-2 from the f32 gradient and the device 1.0e-2 (r04, this instance): the
+    # reference's autocast, which the emulation follows, rounds after every elementwise operation of GCT / WeightedSpatialAttention,
+    # the device's fused kernels round once.  A bar against the emulation alone would fail the device for being closer to the truth.
+    # (yolo11n, this instance: device 1.3e-2 / emulation 1.2e-2 from f32, 6.8e-3 apart.)
     assert loss_rel <= 2e-3, (l1, oloss.item())
-    # whole gradient within 1e-2 of the emulation — or, for a state whose 16-bit error is itself of that order, the device no
-    # farther from the f32 gradient than 1.5x the emulation is (tools/f16_state_probe.py: over 8 trained states the device's
-    # 16-bit error was 0.2-1.1x the emulation's; the emulation is one realisation of the rounding, not the truth)
-    assert (whole <= 1e-2 and cos >= 0.9995) or e_dev <= 1.5 * e_orc, (whole, cos, e_dev, e_orc)
+    assert e_dev <= 2e-2 and whole <= 3e-2 and cos >= 0.9995, (whole, cos, e_dev, e_orc)
     gmax = max(og[k].norm().item() for k in keys)
     rms = fb.norm().item() / len(keys) ** 0.5             # root-mean-square tensor norm: the scale of "a typical tensor"
     # Per tensor: 5 % of its own norm (r03, deterministic: the filters of the 20x20 stages of yolo11n sit at 3.0-3.5 %, everything
@@ -228,8 +238,7 @@ def run_f16_parity(cfg, layers, nc, nb=16, sz=256, steps=200, loss_scale=64.0, s
             nk = og[k].norm().item()
             print(f"f16 parity {cfg}: {k} is {d / nk:.3e} of its norm from the emulation; the emulation's own reorder noise there is "
                   f"{own / nk:.3e}; distance from the f32 gradient: device {ed / nk:.3e}, emulation {eo / nk:.3e}")
-            if d > 2.0 * own and ed > 1.5 * eo:
-                bad.append((k, d, nk, own, ed, eo))
+            bad.append((k, d, nk, own, ed, eo))
     print(f"f16 parity {cfg}: per-tensor worst {max(rel):.3e}, median {float(np.median(rel)):.3e}; largest tensor norm {gmax:.3e}, rms tensor norm {rms:.3e}")
     assert not bad, (floor, bad[:8])
     assert float(np.median(rel)) <= 1e-2, float(np.median(rel))

@@ -123,9 +123,9 @@ def test_fusion_model_train_step_matches_reference_fp32():
 def test_fusion_model_f16_path_matches_f16_emulating_oracle():
     """configs[4]'s dtype on configs[4]'s model: yolo11s_fusion_sand3_new (nc = 2) in f16 against the oracle under emulate_f16
     — the same split and bars as the yolo11n test (tests/_f16_parity.py): assignment bit-exact, criterion gradient on identical
-    logits 1e-3, loss 2e-3, whole gradient 1e-2, per tensor 5 % unless the emulation's own measured noise there is larger."""
+    logits 1e-3, loss 2e-3, whole gradient 1e-2, every tensor 5 % + floor (fixed bars, CPU-trained fixed state)."""
     from tests._f16_parity import run_f16_parity
-    r = run_f16_parity("yolo11s_fusion_sand3_new.yaml", R.resolve_graph("s", nc=2, graph=R.GRAPH_FUSION), nc=2, nb=8, sz=192, steps=150)
+    r = run_f16_parity("yolo11s_fusion_sand3_new.yaml", R.resolve_graph("s", nc=2, graph=R.GRAPH_FUSION), nc=2, nb=8, sz=192)
     print("f16 parity fusion variant:", r)
 
 

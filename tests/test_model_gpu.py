@@ -221,8 +221,8 @@ def test_model_vs_oracle_fresh_inputs_yolo11n():
 def test_f16_path_matches_f16_emulating_oracle_yolo11n():
     """The dtype that is benchmarked.  yolo11n, 16x3x256x256, f16 operands / activations / gradients with f32 accumulation,
     against the oracle under emulate_f16 (same rounding points): assignment bit-exact, criterion gradient on identical logits
-    1e-3, loss 2e-3, whole gradient 1e-2, per-tensor median 1e-2, every tensor 5 % of its norm unless the emulation's own
-    measured noise there is larger.  See tests/_f16_parity.py for the model state, the split and why."""
+    1e-3, loss 2e-3, whole gradient 1e-2, per-tensor median 1e-2, every tensor 5 % of its norm + floor — fixed bars on a state the
+    CPU oracle trainer produced.  See tests/_f16_parity.py for the model state, the split and why."""
     from tests._f16_parity import run_f16_parity
     r = run_f16_parity("yolo11n.yaml", R.resolve_graph("n", nc=80), nc=80)
     print("f16 parity yolo11n:", r)
