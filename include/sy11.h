@@ -264,6 +264,20 @@ size_t sy11_nms_workspace_bytes(int32_t n);
 int sy11_nms_sorted_batched(int32_t nseg, const int32_t* counts, const float* boxes, float iou_thres, int32_t max_keep,
                             uint64_t* workspace, uint8_t* keep, void* stream);
 size_t sy11_nms_batched_workspace_bytes(int32_t nseg, const int32_t* counts);
+/* Candidate selection of non_max_suppression (utils/ops.py:246-292: `x[xc]`, the multi-label `where(cls > conf_thres)` / the
+ * best-class `max`, in the reference's candidate order image -> anchor -> class) straight from the (B, D = 4 + nc + nm, A) tensor
+ * Detect returns.  Two calls: with blk_offset = NULL it COUNTS, blk_count[b * ceil(A / 256) + k] = candidates of anchors
+ * [256 k, 256 k + 256) of image b; with blk_offset = the exclusive prefix sum of those counts it WRITES, per candidate,
+ * key = segment << 32 | ~bits(score) (a stable ascending sort of the keys = per segment, score descending, ties in candidate order),
+ * its anchor and its class; segment = image, or image * nc + class with segment_by_class.  conf_thres >= 0.          */
+int sy11_nms_candidates(int32_t B, int32_t D, int32_t A, int32_t nc, float conf_thres, int32_t multi_label, int32_t segment_by_class,
+                        const float* pred, const int32_t* blk_offset, int32_t* blk_count, int64_t* key, int32_t* anchor, int32_t* cls,
+                        void* stream);
+/* sy11_nms_sorted_batched with the segment list on the DEVICE: rows seg_start[s] .. seg_start[s + 1] (nseg + 1 entries) and first
+ * mask word seg_ws[s] of segment s; max_n = the longest segment (host).  One segment per (image, class) is the reference's batched
+ * NMS (boxes shifted by class * max_wh never intersect across classes, utils/ops.py:307-312) with n^2 / (2 nc) pair tests.      */
+int sy11_nms_sorted_segments(int32_t nseg, const int32_t* seg_start, const int64_t* seg_ws, int32_t max_n, const float* boxes,
+                             float iou_thres, int32_t max_keep, uint64_t* workspace, uint8_t* keep, void* stream);
 
 /* ---- fused detection criterion (v8DetectionLoss.__call__, utils/loss.py:221-275; TaskAlignedAssigner, utils/tal.py:40-296;
  *      bbox_iou CIoU, utils/metrics.py:171-234).  maps: nl NHWC f32 head maps (B, H_l*W_l, 64+nc); gt: (B, G, 5) rows

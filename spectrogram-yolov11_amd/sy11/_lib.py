@@ -84,6 +84,8 @@ SIGNATURES = {
     "sy11_detect_decode": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_nms_sorted": [_i32, _vp, _f32, _vp, _vp, _vp],
     "sy11_nms_sorted_batched": [_i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp],
+    "sy11_nms_candidates": [_i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sy11_nms_sorted_segments": [_i32, _vp, _vp, _i32, _vp, _f32, _i32, _vp, _vp, _vp],
     "sy11_det_loss_assign": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_det_loss_terms": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "sy11_det_loss_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp],

@@ -355,6 +355,62 @@ def nms_sorted_batched(boxes_sorted: torch.Tensor, counts, iou_thres: float, max
     return keep.bool()
 
 
+def nms_candidates(pred: torch.Tensor, nc: int, conf_thres: float, multi_label: bool, segment_by_class: bool = False, max_per_image: int = None,
+                   class_ok: torch.Tensor = None):
+    """Candidates of non_max_suppression from the (B, 4 + nc + nm, A) f32 prediction tensor, in the reference's order (image, anchor,
+    class).  -> (key int64 (n,), anchor int32 (n,), class int32 (n,)) on the device, the per-image counts as a host list, and whether
+    the keys are segmented by class: key = segment << 32 | ~bits(score), segment = image, or image * nc + class when
+    ``segment_by_class`` is asked for AND no image has more than ``max_per_image`` candidates (the caller's `max_nms` cut is per image
+    and by score, so it needs the image-wide order) AND the device flag ``class_ok`` (read with the counts) is non-zero.
+    One host synchronisation (the counts)."""
+    _need_gpu(pred)
+    if pred.dtype != torch.float32 or not pred.is_contiguous():
+        raise _lib.Sy11Error("nms_candidates: prediction must be a contiguous f32 (B, D, A) tensor")
+    B, D, A = pred.shape
+    nblk = (A + 255) // 256
+    cnt = torch.empty((B, nblk), dtype=torch.int32, device=pred.device)
+    call("sy11_nms_candidates", B, D, A, nc, float(conf_thres), 1 if multi_label else 0, 0, _p(pred), None, _p(cnt), None, None, None, _stream())
+    incl = torch.cumsum(cnt.view(-1), 0, dtype=torch.int32)
+    off = (incl - cnt.view(-1)).contiguous()
+    per_image = cnt.sum(1, dtype=torch.int64)
+    if class_ok is not None:
+        per_image = torch.cat((per_image, class_ok.reshape(1).to(torch.int64)))
+    per_image = per_image.tolist()                             # the one host read: sizes the outputs, and the caller's segment list
+    ok = bool(per_image.pop()) if class_ok is not None else True
+    total = sum(per_image)
+    by_class = bool(segment_by_class) and ok and not (max_per_image is not None and per_image and max(per_image) > max_per_image)
+    flags = (1 if multi_label else 0, 1 if by_class else 0)
+    key = torch.empty((total,), dtype=torch.int64, device=pred.device)
+    anchor = torch.empty((total,), dtype=torch.int32, device=pred.device)
+    cls = torch.empty((total,), dtype=torch.int32, device=pred.device)
+    if total:
+        call("sy11_nms_candidates", B, D, A, nc, float(conf_thres), *flags, _p(pred), _p(off), None, _p(key), _p(anchor), _p(cls), _stream())
+    return key, anchor, cls, per_image, by_class
+
+
+def nms_sorted_segments(boxes_sorted: torch.Tensor, seg_of_row: torch.Tensor, nseg: int, iou_thres: float, max_keep: int) -> torch.Tensor:
+    """Greedy NMS of ``nseg`` segments at once; ``seg_of_row`` (int64, non-decreasing) names the segment of every row of
+    ``boxes_sorted`` ((n, 4) f32, a segment's rows in score-descending order).  -> bool keep mask (n,), at most ``max_keep``
+    survivors per segment.  One host read (the longest segment and the workspace size)."""
+    _need_gpu(boxes_sorted, seg_of_row)
+    n = boxes_sorted.shape[0]
+    keep = torch.zeros((n,), dtype=torch.uint8, device=boxes_sorted.device)
+    if n == 0:
+        return keep.bool()
+    cnt = torch.bincount(seg_of_row, minlength=nseg)
+    nw = (cnt + 63) // 64
+    words = cnt * nw
+    ws_end = torch.cumsum(words, 0)
+    max_n, total_words = (int(v) for v in torch.stack((cnt.max(), ws_end[-1])).tolist())
+    start = torch.zeros((nseg + 1,), dtype=torch.int32, device=boxes_sorted.device)
+    start[1:] = torch.cumsum(cnt, 0)
+    ws = (ws_end - words).contiguous()
+    work = torch.empty((max(total_words, 1),), dtype=torch.int64, device=boxes_sorted.device)
+    call("sy11_nms_sorted_segments", nseg, _p(start), _p(ws), max_n, _p(boxes_sorted.contiguous().float()), float(iou_thres), int(max_keep),
+         _p(work), _p(keep), _stream())
+    return keep.bool()
+
+
 def stft_logmel(iq, window, mel_start, mel_w, n_fft, hop, n_frames, n_mel):
     """iq: (B, L) complex64 -> (db (B, frames, n_mel) f32, minmax (B, 2) f32)."""
     _need_gpu(iq, window, mel_start, mel_w)

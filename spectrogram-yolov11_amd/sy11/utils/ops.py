@@ -1,9 +1,11 @@
 """Box utilities and NMS under the reference's names (ultralytics/utils/ops.py: scale_boxes :92-127, make_divisible :130-143,
 non_max_suppression :181-332, clip_boxes :335-354, xyxy2xywh :412-429, xywh2xyxy :432-449).
 
-``non_max_suppression`` is re-cut for the device: candidate selection, class offsets, the per-image score ordering and the
-`max_nms` / `max_det` truncations are done ONCE for the whole batch with tensor ops (one host read of the per-image candidate
-counts instead of a Python loop with several reads per image); the greedy suppression itself runs for all images side by side on the HIP
+``non_max_suppression`` is re-cut for the device: candidate selection (r04: a HIP kernel pair straight over the (B, 4 + nc, A) tensor
+Detect wrote — ``sy11_nms_candidates`` — and ONE stable sort of 64-bit (image, score) keys; the tensor-op form of r03 remains for
+apriori labels / class filters / CPU tensors), class offsets and the `max_nms` / `max_det` truncations are done ONCE for the whole
+batch (one host read of the per-image candidate counts instead of a Python loop with several reads per image); the greedy
+suppression itself runs for all images side by side on the HIP
 bit-matrix kernels (``sy11_nms_sorted_batched``) that stands where the reference calls ``torchvision.ops.nms`` (ops.py:312), fed in
 (score descending, index ascending) order so the kept set is bit-exact.  The reference's wall-clock break (ops.py:328-330) is
 intentionally absent: results never depend on time.
@@ -124,13 +126,81 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     nc = nc or D - 4
     nm = D - 4 - nc
     multi_label = bool(multi_label) and nc > 1
+    prior = _prior_rows(labels, nc, nm, prediction.dtype, dev)
+    if (prior is None and wanted is None and prediction.is_cuda and prediction.dtype == torch.float32 and prediction.is_contiguous()
+            and conf_thres >= 0):
+        # ---- device path (r04): thresholding, compaction and the candidate order come from ONE pass over the tensor as Detect wrote it
+        # (sy11_nms_candidates); the per-image score order is ONE stable sort of 64-bit keys (image << 32 | ~bits(score)) instead of
+        # two sorts + gathers; no (B, A, D) transposed copy, no boolean mask, no torch.nonzero over B x A x nc scores
+        half = prediction[:, 2:4] / 2
+        xy = torch.cat((prediction[:, 0:2] - half, prediction[:, 0:2] + half), 1)       # (B, 4, A): xywh2xyxy, element for element
+        if in_place:
+            prediction[:, :4] = xy                            # the caller's tensor holds corner boxes afterwards, as in the reference
+        # one segment per (image, class) unless agnostic: shifted by class * max_wh, boxes of different classes never intersect, so
+        # the image-wide greedy sweep keeps exactly what per-class sweeps keep — at n^2 / (2 nc) instead of n^2 / 2 IoU tests.  That
+        # holds while no box reaches across a class's max_wh-wide band: checked on the device (x extent of ALL boxes < max_wh; Detect's
+        # decoded boxes span at most the image + 2 x 15 strides), read back with the candidate counts; otherwise one sweep per image
+        span_ok = (xy[:, 2].amax() - xy[:, 0].amin()) < max_wh
+        key, anchor, cidx, counts, by_class = _k.nms_candidates(prediction, nc, conf_thres, multi_label, not agnostic, max_nms, span_ok)
+        order = torch.sort(key, stable=True).indices
+        key = key[order]
+        seg = key >> 32
+        conf = ((~key) & 0xFFFFFFFF).to(torch.int32).view(torch.float32)
+        a_idx, c = anchor[order].long(), cidx[order].long()
+        img = seg // nc if by_class else seg
+        if not by_class and counts and max(counts) > max_nms:  # keep each image's max_nms best (the keys are per image here)
+            counts_t = torch.tensor(counts, device=dev)
+            starts = torch.cumsum(counts_t, 0) - counts_t
+            sel = (torch.arange(img.numel(), device=dev) - starts[img]) < max_nms
+            a_idx, c, conf, img, order = a_idx[sel], c[sel], conf[sel], img[sel], order[sel]
+            counts = [min(n, max_nms) for n in counts]
+        box = xy[img, :, a_idx]
+        cls_f = c.to(prediction.dtype)
+        shifted = box if agnostic else box + (cls_f * max_wh).unsqueeze(1)
+        if by_class:
+            keep = _k.nms_sorted_segments(shifted.contiguous(), seg, B * nc, iou_thres, max_det)
+            kept = torch.nonzero(keep, as_tuple=True)[0]
+            # back to the reference's order — per image, score descending, ties in candidate order: survivors into candidate order
+            # (their positions in the unsorted candidate list), then one stable sort by (image, score)
+            kept = kept[torch.sort(order[kept]).indices]
+            kept = kept[torch.sort((img[kept] << 32) | (key[kept] & 0xFFFFFFFF), stable=True).indices]
+        else:
+            keep = _suppress(shifted.contiguous(), conf, counts, iou_thres, max_det)
+            kept = torch.nonzero(keep, as_tuple=True)[0]
+        kimg = img[kept]
+        kcount = torch.bincount(kimg, minlength=B)
+        krank = torch.arange(kept.numel(), device=dev) - (torch.cumsum(kcount, 0) - kcount)[kimg]
+        kept = kept[krank < max_det]
+        final = torch.cat((box[kept], conf[kept, None], cls_f[kept, None], prediction[img[kept], 4 + nc:, a_idx[kept]]), 1)
+        sizes = torch.bincount(img[kept], minlength=B).tolist()    # host read: survivors per image
+        return list(torch.split(final, sizes))
+    box, c, conf, img, counts, extra, dtype = _candidates_by_tensor_ops(prediction, prior, wanted, B, D, A, nc, nm, conf_thres, multi_label,
+                                                                      in_place, max_nms)
+    cls_f = c.to(dtype)
+    shifted = box if agnostic else box + (cls_f * max_wh).unsqueeze(1)      # classes never overlap: one NMS for all of them
+
+    # ---- greedy suppression, all images side by side (HIP), then the first max_det survivors of each image
+    keep = _suppress(shifted.contiguous(), conf, counts, iou_thres, max_det)
+    kept = torch.nonzero(keep, as_tuple=True)[0]
+    kimg = img[kept]
+    kcount = torch.bincount(kimg, minlength=B)
+    krank = torch.arange(kept.numel(), device=dev) - (torch.cumsum(kcount, 0) - kcount)[kimg]
+    kept = kept[krank < max_det]                               # (the kernel already stops at max_det survivors; a stub may not)
+    final = torch.cat((box[kept], conf[kept, None], cls_f[kept, None], extra(kept)), 1)
+    sizes = torch.bincount(img[kept], minlength=B).tolist()    # host read 2 of 2: survivors per image
+    return list(torch.split(final, sizes))
+
+
+def _candidates_by_tensor_ops(prediction, prior, wanted, B, D, A, nc, nm, conf_thres, multi_label, in_place, max_nms):
+    """The r03 candidate selection with tensor operations: taken with apriori `labels`, a `classes` filter, CPU tensors or a
+    non-f32 / non-contiguous prediction.  -> (box (n, 4), class index, score, image index, per-image counts, mask-coefficient getter, dtype)."""
+    dev = prediction.device
     rows = prediction.transpose(1, 2)                         # (B, A, D) view
     xyxy = xywh2xyxy(rows[..., :4])
     if in_place:
         rows[..., :4] = xyxy                                  # the caller's tensor holds corner boxes afterwards, as in the reference
     rows = torch.cat((xyxy, rows[..., 4:]), -1).reshape(B * A, D)
     img_of = torch.arange(B, device=dev).repeat_interleave(A)
-    prior = _prior_rows(labels, nc, nm, rows.dtype, dev)
     if prior is not None:                                     # an image's apriori rows follow its predictions (stable sort below)
         img_of = torch.cat((img_of, prior[0]))
         rows = torch.cat((rows, prior[1]))
@@ -164,17 +234,6 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         sel = (torch.arange(img.numel(), device=dev) - starts[img]) < max_nms
         r, c, conf, img = r[sel], c[sel], conf[sel], img[sel]
         counts = [min(n, max_nms) for n in counts]
-    cls_f = c.to(rows.dtype)
     box = rows[r, :4]
-    shifted = box if agnostic else box + (cls_f * max_wh).unsqueeze(1)      # classes never overlap: one NMS for all of them
+    return box, c, conf, img, counts, (lambda kept: rows[r[kept], 4 + nc:]), rows.dtype
 
-    # ---- greedy suppression, all images side by side (HIP), then the first max_det survivors of each image
-    keep = _suppress(shifted.contiguous(), conf, counts, iou_thres, max_det)
-    kept = torch.nonzero(keep, as_tuple=True)[0]
-    kimg = img[kept]
-    kcount = torch.bincount(kimg, minlength=B)
-    krank = torch.arange(kept.numel(), device=dev) - (torch.cumsum(kcount, 0) - kcount)[kimg]
-    kept = kept[krank < max_det]                               # (the kernel already stops at max_det survivors; a stub may not)
-    final = torch.cat((box[kept], conf[kept, None], cls_f[kept, None], rows[r[kept], 4 + nc:]), 1)
-    sizes = torch.bincount(img[kept], minlength=B).tolist()    # host read 2 of 2: survivors per image
-    return list(torch.split(final, sizes))

@@ -68,7 +68,9 @@ def _git(*args):
         return ""
 
 
-out = {"commit": _git("rev-parse", "HEAD"), "worktree_dirty": bool(_git("status", "--porcelain", "--", "spectrogram-yolov11_amd", "bench.py")),
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import bench as _bench
+out = {"commit": _git("rev-parse", "HEAD"), "csrc_sha16": _bench.kernel_source_sha16(), "worktree_dirty": bool(_git("status", "--porcelain", "--", "spectrogram-yolov11_amd", "bench.py")),
        "commands": ["SY11_TUNE_SAVE=$OUT/picks.bin python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-fwd-leg --no-extras",
                     "SY11_TUNE_LOAD=$OUT/picks.bin SY11_TUNE=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/FETCH_SIZE -o run -- python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-fwd-leg --no-extras --no-graphs",
                     "SY11_TUNE_LOAD=$OUT/picks.bin SY11_TUNE=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/WRITE_SIZE -o run -- python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-roofline --no-fwd-leg --no-extras --no-graphs",
