@@ -83,6 +83,9 @@ int sy11_peak_mfma_f16(int32_t workgroups, int32_t iters, float* out, void* stre
  * elements: the per-workgroup records {entry, exit (100 MHz ticks), XCC id, cycles of the four kernel sections, 0} of the first 2048
  * workgroups follow.                                                                                                      */
 int sy11_debug_stamps(uint64_t* out16);
+/* ... and of its persistent form (csrc/igemm8p.hip): per workgroup (256) {cycles waiting for the first stages, main loops, next-tile
+ * addresses + first copies, epilogues, tiles, 100 MHz ticks from start to end, 0, 0} -> 2048 values on the host.                  */
+int sy11_debug_stamps_persistent(uint64_t* out2048);
 
 /* ---- convolution (replaces nn.Conv2d inside Conv.forward / forward_fuse, nn/modules/conv.py:79-83,
  *      and the bare nn.Conv2d heads of Detect, nn/modules/head.py:44-55) -------------------------------- */

@@ -526,10 +526,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ?
 // 20, 21 = 8-wave software pipeline (igemm8.hip): 256 pixels x 128 / 64 channels, 128-byte K stages in 3 LDS slots, one workgroup per CU
 // 22, 23 = the same with 64-byte K stages in 6 slots (twice the prefetch distance in cycles)
 // 24 = 256 pixels x 256 channels (wave tile 128 x 64): 64 FLOP per filled byte instead of 43
+// 25 = configuration 20 as PERSISTENT workgroups (igemm8p.hip): the next tile's first stages in flight under the current tile's epilogue
 constexpr int IGEMM_NCFG = SY11_IGEMM_NCFG;
-static_assert(IGEMM_NCFG == 25, "configuration table and its size (tune.h) out of step");
+static_assert(IGEMM_NCFG == 26, "configuration table and its size (tune.h) out of step");
 bool sy11_igemm8_legal(const IgemmArgs& a, int bn, int kb, int epi);
 int sy11_igemm8_launch(const IgemmArgs& a, int bn, int kb, int epi, hipStream_t st);
+bool sy11_igemm8p_legal(const IgemmArgs& a, int epi);
+int sy11_igemm8p_launch(const IgemmArgs& a, int epi, hipStream_t st);
 static int halo_bn(const IgemmArgs& a, int cfg) {
   const int wide = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
   const int bn = (cfg == 15 || cfg == 17) ? wide : (wide > 32 ? wide / 2 : 0);
@@ -550,6 +553,7 @@ static bool cfg_legal(const IgemmArgs& a, int cfg) {
     return std::is_same<T, _Float16>::value && bn > 0 && sy11_halo3x3_legal(a, bn);
   }
   if (cfg == 19) return !std::is_same<T, float>::value && sy11_smallc3x3_legal(a);
+  if (cfg == 25) return std::is_same<T, _Float16>::value && sy11_igemm8p_legal(a, epi_code(a));
   if (cfg >= 20 && cfg <= 24) return std::is_same<T, _Float16>::value && sy11_igemm8_legal(a, cfg == 24 ? 256 : ((cfg & 1) ? 64 : 128), cfg < 22 ? 128 : 64, epi_code(a));
   if (cfg == 7 || cfg == 8) {
     const int epi = epi_code(a), bn = cfg == 7 ? 128 : 64;
@@ -578,9 +582,9 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
   if (cfg == 7 || cfg == 8)
     return sy11_igemm1x1p_launch(ElemTraits<T>::code, a.x, a.w, a.y, a.stat_sum, a.stat_sq, a.M, a.N, a.K, a.x_ld, a.y_ld, a.stat_slots,
                                  a.stat_stride, a.x_bytes, a.w_bytes, epi_code(a), a.debug == 5 ? 1 : 0, cfg == 7 ? 128 : 64, st, a.bias);
-  const bool wave8 = cfg >= 20 && cfg <= 24;
+  const bool wave8 = cfg >= 20 && cfg <= 25;
   const int bm = (cfg == 3 || wave8) ? 256 : 128;
-  const int tile = wave8 ? (cfg & 1) : (cfg >= 12 ? cfg - 12 : (cfg >= 9 ? cfg - 9 : (cfg >= 4 ? cfg - 4 : cfg)));
+  const int tile = cfg == 25 ? 0 : wave8 ? (cfg & 1) : (cfg >= 12 ? cfg - 12 : (cfg >= 9 ? cfg - 9 : (cfg >= 4 ? cfg - 4 : cfg)));
   const int bn = cfg == 24 ? 256 : (tile == 1 ? 64 : (tile == 2 ? 32 : 128));
   a.tiles_n = cdiv(a.N, bn);
   const long nwg = (long)cdiv(a.M, bm) * a.tiles_n;
@@ -624,7 +628,7 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
     }                                                            \
   } while (0)
   if (wave8) {
-    const int rc8 = sy11_igemm8_launch(a, bn, cfg < 22 ? 128 : 64, epi_pre, st);
+    const int rc8 = cfg == 25 ? sy11_igemm8p_launch(a, epi_pre, st) : sy11_igemm8_launch(a, bn, cfg < 22 ? 128 : 64, epi_pre, st);
     if (rc8) return rc8;
   } else if (bm == 256) {
     if constexpr (std::is_same<T, _Float16>::value) {
@@ -679,7 +683,7 @@ static int select_and_launch(IgemmArgs& a, hipStream_t st) {
     } else if (sy11tune::enabled() && !sy11tune::capturing(st)) {
       int cands[IGEMM_NCFG], nc = 0;
       for (int c = 0; c < IGEMM_NCFG; ++c) {
-        const int ct = c >= 20 ? (c & 1) : (c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c))));
+        const int ct = c == 25 ? 0 : c >= 20 ? (c & 1) : (c >= 12 ? c - 12 : (c >= 9 ? c - 9 : (c >= 7 ? (c == 7 ? 0 : 1) : (c >= 4 ? c - 4 : c))));
         const int cbn = c == 24 ? 256 : (ct == 1 ? 64 : (ct == 2 ? 32 : 128));
         if ((c < 15 || c >= 20) && cbn > 32 && cbn >= 2 * a.N) continue;              // tile more than twice the channel count: pure waste
         if (cfg_legal<T>(a, c)) cands[nc++] = c;

@@ -106,6 +106,7 @@ SIGNATURES.update({
     "sy11_tune_clear": [],
     "sy11_peak_mfma_f16": [_i32, _i32, _vp, _vp],
     "sy11_debug_stamps": [_vp],
+    "sy11_debug_stamps_persistent": [_vp],
     "sy11_opt_workspace_floats": [_i32],
     "sy11_opt_grad_norm": [_i64, _vp, _vp, _vp, _vp, _i32, _vp],
     "sy11_opt_step": [_op, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

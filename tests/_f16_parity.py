@@ -77,6 +77,25 @@ def pretrained_state(cfg, layers, nc, nb, sz, steps, seed=11):
     return sd
 
 
+def device_pretrained_state(cfg, nc, nb, sz, steps, seed=11):
+    """The r03 form: the constructor's initialisation after ``steps`` f32 SGD steps ON THE DEVICE.  Not an input of the f16 parity tests any
+    more (a kernel change would change it); tests/test_config2_gpu.py and the probes under tools/ use it where a trained state of a model
+    too large for the CPU trainer is wanted and nothing is compared against a fixed instance."""
+    from sy11.engine.trainer import DetectionTrainer
+    from sy11.nn.tasks import DetectionModel
+    torch.manual_seed(seed)
+    m0 = DetectionModel(cfg, ch=3, nc=nc, verbose=False)
+    tr = DetectionTrainer(m0, batch_size=nb, device=DEV, overrides={"amp": False, "nbs": nb, "warmup_epochs": 0}, graphs=False)
+    g = torch.Generator().manual_seed(seed)
+    for _ in range(steps):
+        n = 3 * nb
+        b = {"img": torch.rand(nb, 3, sz, sz, generator=g).to(DEV), "batch_idx": torch.arange(nb).repeat_interleave(3).float().to(DEV),
+             "cls": torch.randint(0, nc, (n, 1), generator=g).float().to(DEV),
+             "bboxes": torch.cat((0.25 + 0.5 * torch.rand(n, 2, generator=g), 0.1 + 0.4 * torch.rand(n, 2, generator=g)), 1).to(DEV)}
+        tr.train_step(b)
+    return {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+
+
 def oracle_assignment(maps_nchw, batch, nc):
     """TaskAlignedAssigner outputs (oracle) for head maps given as NCHW f32 CPU tensors."""
     with torch.no_grad():

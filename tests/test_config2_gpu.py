@@ -41,7 +41,7 @@ def test_iq_to_graph_replayed_train_step_bs64_640():
     torch.manual_seed(0)
     # weights: initialisation + 150 f32 SGD steps at 16x3x256x256 (tests/_f16_parity.py): at initialisation every anchor predicts
     # its bias whatever the image shows, and "the replay computed on the new image" would show nowhere in the loss
-    from tests._f16_parity import pretrained_state
+    from tests._f16_parity import device_pretrained_state as pretrained_state
     sd = pretrained_state("yolo11s.yaml", 80, nb=16, sz=256, steps=150)
     prod = SpectrogramProducer(DEV)
     t_iq, t_img = make_trainer(sd, prod), make_trainer(sd, None)

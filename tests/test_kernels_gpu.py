@@ -169,7 +169,7 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
     tune0 = _lib.get_option("tune")
     try:
         _lib.set_option("tune", 0)
-        for cfg in range(25):
+        for cfg in range(26):
             _lib.set_option("igemm_cfg", cfg)
             y = torch.empty(B, OH, OW, N, dtype=dtype, device=DEV)
             ssum, ssq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
@@ -270,8 +270,9 @@ def test_eight_wave_pipeline_epilogues_and_tails(case):
     korder0 = _lib.get_option("igemm_korder")
     try:
         # K order x (128-byte stages in 3 slots | 64-byte stages in 6 slots | the 256 x 256 tile where the layer has > 128 channels)
-        for korder, kb64 in ((1, 0), (0, 0), (1, 2), (0, 2), (1, 4), (0, 4)):
-            cfg = 24 if (kb64 == 4 and N > 128) else (20 if N > 64 else 21) + (kb64 & 2)
+        # ... | the persistent form of cfg 20, kb64 = 8)
+        for korder, kb64 in ((1, 0), (0, 0), (1, 2), (0, 2), (1, 4), (0, 4), (1, 8), (0, 8)):
+            cfg = 25 if (kb64 == 8 and N > 64) else 24 if (kb64 == 4 and N > 128) else (20 if N > 64 else 21) + (kb64 & 2)
             _lib.set_option("igemm_korder", korder)
             _lib.set_option("igemm_cfg", cfg)
             wide_y = torch.full((B, OH, OW, N + 24), 7.0, dtype=dtype, device=DEV)
@@ -286,7 +287,7 @@ def test_eight_wave_pipeline_epilogues_and_tails(case):
             o.conv2d_fwd(xv, wk, y2, k, s, p, bias=bias.to(DEV), silu=True)
             close(to_nchw(y2), F.silu(ref + bias.view(1, -1, 1, 1)), dtype, "bias + SiLU", mult=2)
             # input gradient: the same kernel on dy (C and N swap roles: legal when C > 32 ... ) — plain, then accumulated
-            _lib.set_option("igemm_cfg", 24 if (kb64 == 4 and Cn > 128) else (20 if Cn > 64 else 21) + (kb64 & 2))
+            _lib.set_option("igemm_cfg", 25 if (kb64 == 8 and Cn > 64) else 24 if (kb64 == 4 and Cn > 128) else (20 if Cn > 64 else 21) + (kb64 & 2))
             dx = torch.zeros(B, H, W, Cn, dtype=dtype, device=DEV)
             o.conv2d_dgrad(nhwc(dy, dtype), wt, dx, (B, OH, OW, N), k, s, p, accumulate=(s > 1))
             close(to_nchw(dx), ref_dx, dtype, f"dgrad (korder {korder})")

@@ -9,7 +9,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "spectrogram-yolov1
 os.environ.setdefault("SY11_DETERMINISTIC", "1")
 import torch
 from sy11 import _lib
-from tests._f16_parity import pretrained_state, pinned_device_step, GAINS, DEV
+from tests._f16_parity import device_pretrained_state as pretrained_state, pinned_device_step, GAINS, DEV
 from types import SimpleNamespace
 from sy11.nn.tasks import DetectionModel
 

@@ -12,7 +12,7 @@ import torch
 from oracle import loss_ref
 from sy11 import _lib
 from sy11.nn.tasks import DetectionModel
-from tests._f16_parity import pretrained_state, pinned_device_step, oracle_assignment, device_targets, GAINS, DEV, STRIDES
+from tests._f16_parity import device_pretrained_state as pretrained_state, pinned_device_step, oracle_assignment, device_targets, GAINS, DEV, STRIDES
 
 states = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 cfg, nc, nb, sz = "yolo11n.yaml", 80, 16, 256

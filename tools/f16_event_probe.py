@@ -11,7 +11,7 @@ from types import SimpleNamespace
 import torch
 from sy11 import _lib
 from sy11.nn.tasks import DetectionModel
-from tests._f16_parity import pretrained_state, pinned_device_step, GAINS, DEV
+from tests._f16_parity import device_pretrained_state as pretrained_state, pinned_device_step, GAINS, DEV
 
 states = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 12

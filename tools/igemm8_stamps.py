@@ -23,6 +23,15 @@ for (H, W, Cc, N, k, s) in SHAPES:
     for _ in range(3):
         ops.conv2d_fwd(x, w, y, k, s, p, stats=(st[0], st[1]))
     torch.cuda.synchronize()
+    if CFG == 25:
+        pb = (C.c_uint64 * 2048)()
+        _lib.check(_lib.load().sy11_debug_stamps_persistent(pb), "sy11_debug_stamps_persistent")
+        rec = [list(pb)[8 * i:8 * i + 8] for i in range(256)]
+        rec = [r for r in rec if r[4]]
+        med = lambda k: sorted(r[k] / r[4] for r in rec)[len(rec) // 2]
+        print(f"{H}x{W} {Cc}->{N} k{k}s{s}: persistent, {len(rec)} workgroups, {sum(r[4] for r in rec)} tiles; median cycles per tile: first-stage wait {med(0):.0f}, "
+              f"main loop {med(1):.0f}, next-tile setup + issue {med(2):.0f}, epilogue {med(3):.0f}; workgroup span {sorted(r[5] for r in rec)[len(rec) // 2] / 100:.1f} us")
+        continue
     buf = (C.c_uint64 * (16 + 8 * 2048))()
     buf[0] = 1
     _lib.check(_lib.load().sy11_debug_stamps(buf), "sy11_debug_stamps")
