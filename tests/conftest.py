@@ -18,7 +18,34 @@ os.environ.setdefault("SY11_TUNE", "0")
 os.environ.setdefault("SY11_DETERMINISTIC", "1")
 
 
+def _usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota.  A GPU box hands a job 16 CPUs of a host whose
+    every core stays visible: torch then starts one thread per VISIBLE core and the CPU oracle (which most `-m gpu` tests run beside the
+    device) crawls under the quota — r04: the two f16 parity tests took 675 s on the box against ~80 s in the 8-CPU build container."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:                                   # noqa: BLE001
+        pass
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:                               # noqa: BLE001
+            continue
+    return n
+
+
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(max(1, min(_usable_cpus(), 32)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
