@@ -65,8 +65,19 @@ class Materializer:
     dataset index as a device tensor; resized / letterboxed nodes are kept in a small LRU so that the mosaic partners a worker keeps
     re-drawing from its buffer are produced once."""
 
-    def __init__(self, fetch, device, capacity=4096):
+    def __init__(self, fetch, device, capacity=4096, max_bytes=None):
         self.fetch, self.device, self.capacity = fetch, torch.device(device), capacity
+        # bounded by BYTES as well as by entries (ADVICE r03): the cache holds raw decoded sources of any resolution next to their
+        # letterboxed copies; the reference bounds its buffer to min(n, 8 x batch, 1000) already-resized images (data/base.py:98-104).
+        # Default budget: an eighth of the device memory that is free when the loader is built, at most 8 GiB.
+        if max_bytes is None:
+            max_bytes = 2 << 30
+            if self.device.type == "cuda":
+                try:
+                    max_bytes = min(torch.cuda.mem_get_info(self.device)[0] // 8, 8 << 30)
+                except Exception:                             # noqa: BLE001 — no usable device query: keep the fixed budget
+                    pass
+        self.max_bytes, self.bytes = int(max_bytes), 0
         self.cache = {}
 
     def __call__(self, node):
@@ -89,8 +100,17 @@ class Materializer:
         else:
             raise ValueError(f"unknown lazy image op {kind!r}")
         if key is not None:
-            if len(self.cache) >= self.capacity:
-                for k in list(self.cache)[: self.capacity // 4]:       # insertion order = age: drop the oldest quarter
-                    del self.cache[k]
-            self.cache[key] = out
+            size = out.numel() * out.element_size()
+            if len(self.cache) >= self.capacity or self.bytes + size > self.max_bytes:
+                # insertion order = age: drop the oldest quarter of the entries, and keep dropping until the newcomer fits
+                drop = max(len(self.cache) // 4, 1)
+                for k in list(self.cache):
+                    if drop <= 0 and self.bytes + size <= self.max_bytes:
+                        break
+                    v = self.cache.pop(k)
+                    self.bytes -= v.numel() * v.element_size()
+                    drop -= 1
+            if size <= self.max_bytes:
+                self.cache[key] = out
+                self.bytes += size
         return out

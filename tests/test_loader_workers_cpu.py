@@ -123,3 +123,18 @@ def test_a_dead_worker_raises_instead_of_hanging(tmp_path):
                 next(it)
     finally:
         dl.close()
+
+
+def test_materializer_cache_is_bounded_by_bytes():
+    """the source cache was bounded by entry count only (raw decoded images of any resolution in HBM).  It now also
+    carries a byte budget: the oldest entries go first, an image larger than the whole budget is not cached at all."""
+    from sy11.data.recipe import Materializer, file_image
+    one = 100 * 100 * 3
+    m = Materializer(lambda i: torch.zeros(100, 100, 3, dtype=torch.uint8), "cpu", capacity=1000, max_bytes=10 * one)
+    for i in range(50):
+        m(file_image(i, (100, 100)))
+        assert m.bytes <= m.max_bytes and m.bytes == sum(v.numel() for v in m.cache.values())
+    assert 1 <= len(m.cache) <= 10 and file_image(49, (100, 100)).key() in m.cache          # the newest survives, the oldest went
+    big = Materializer(lambda i: torch.zeros(400, 400, 3, dtype=torch.uint8), "cpu", max_bytes=one)
+    big(file_image(0, (400, 400)))
+    assert len(big.cache) == 0 and big.bytes == 0
