@@ -11,7 +11,7 @@ Rank 0 prints ONE JSON line.
 Besides the headline (`value`, configs[2]) the line carries, all measured after the timed region and never part of `value`:
   roofline      the kernel family with the largest share of the step (HIP events around every C-ABI launch of one instrumented
                 step, issued behind a head-start delay so that the GPU never waits for the host between launches), its algorithmic
-                bytes / FLOPs, the HBM traffic of the same family from the rocprofv3 PMC passes (profiles/r02/traffic.json);
+                bytes / FLOPs, the HBM traffic of the same family from the rocprofv3 PMC passes (profiles/r04/traffic.json, quoted only when measured on this csrc);
   peaks         measured on this GPU in this run: pure-MFMA loop (sy11_peak_mfma_f16) and a 1 GiB device-to-device copy;
   cpu_baseline  the oracle (CPU restatement of the reference path) on the host cores: 7 threads (the reference's default
                 min(8, ncpu - 1)) and all cores, eval forward and train step;
