@@ -10,7 +10,7 @@
 // sizes of the two tile-configuration tables (igemm.hip / wgrad.hip own the meaning of an index; core.hip validates imported picks
 // against these — ONE definition, so that adding a configuration cannot leave the importer behind)
 constexpr int SY11_IGEMM_NCFG = 26;
-constexpr int SY11_WGRAD_NCFG = 16;
+constexpr int SY11_WGRAD_NCFG = 20;
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

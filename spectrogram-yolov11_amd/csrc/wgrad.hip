@@ -394,6 +394,150 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ wide tile (r04)
+// wgrad16_kernel<128> is bound by the L2 -> LDS fill (r04 stamps: ~40-55 GB/s per CU whatever the schedule): 64 pixels x (128 + 128)
+// columns per stage = 32 MAC per staged byte.  This variant owns a 128-filter x 256-column block of dW with EIGHT waves (2 x 4, 64 x 64
+// each, the same fragment code): 64 x (128 + 256) per stage = 42.7 MAC per byte, a third fewer staged bytes per FLOP; 113 KB of LDS
+// (two stages), one workgroup per CU.  Staging is the same branch-free register path; the dy and x tiles have different chunk
+// geometries (16 / 32 chunks per row), so each thread keeps two (row, chunk) roles.
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad16w_kernel(const WgradArgs a) {
+  constexpr int TN = 128, TK = 256, BP = 64;
+  constexpr int ROWN = TN * 2 + 64, ROWK = TK * 2 + 64;      // LDS row strides in bytes (64 mod 128: the transposing reads stay conflict-free)
+  constexpr int OPN = BP * ROWN, OPK = BP * ROWK;
+  constexpr int NPN = 2, NPK = 4;                            // passes: 512 threads cover 32 dy rows / 16 x rows at a time
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_xcd = gridDim.x >> 3;
+  const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (vid >= a.total) return;
+  const int split = vid / a.tiles, tile = vid - split * a.tiles;
+  const int tile_k = tile % a.tiles_k, tile_n = tile / a.tiles_k;
+  const int n0 = tile_n * TN, k0 = tile_k * TK;
+  const int m_begin = split * a.pix_per_split;
+  const int m_end = min(a.M, m_begin + a.pix_per_split);
+  float* const dwp = a.dw + (long)split * a.dw_split_stride;
+  if (m_begin >= m_end) return;
+
+  const int chunk_n = tid & 15, prow_n = tid >> 4;           // dy role
+  const int chunk_k = tid & 31, prow_k = tid >> 5;           // x role
+  const int ncol = n0 + chunk_n * 8;
+  const int kk = k0 + chunk_k * 8;
+  const bool k_ok = kk < a.K;
+  const int kt = k_ok ? kk / a.C : 0, kc = k_ok ? kk - kt * a.C : 0;
+  const int tdy = a.tap_dy[kt], tdx = a.tap_dx[kt];
+  const int ohw = a.OH * a.OW;
+
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  int pb[NPK], py[NPK], px[NPK];
+#pragma unroll
+  for (int p = 0; p < NPK; ++p) {
+    const int m = m_begin + prow_k + p * 16;
+    const int mm = m < a.M ? m : 0;
+    pb[p] = mm / ohw;
+    const int r = mm - pb[p] * ohw;
+    py[p] = r / a.OW;
+    px[p] = r - py[p] * a.OW;
+  }
+  const int dy_col = ncol < a.N ? ncol * 2 : -1, x_col = k_ok ? kc * 2 : -1;
+  const int dy_rowb = a.dy_ld * 2, x_pixb = a.x_ld * 2;
+  uint4 rdy[NPN], rx[NPK];
+  auto load_stage = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < NPN; ++p) {
+      const int m = m0 + prow_n + p * 32;
+      const unsigned od = (m < m_end && dy_col >= 0) ? (unsigned)(m * dy_rowb + dy_col) : OOB;
+      const u4 vd = __builtin_amdgcn_raw_buffer_load_b128(dr, od, 0, 0);
+      rdy[p] = make_uint4(vd[0], vd[1], vd[2], vd[3]);
+    }
+#pragma unroll
+    for (int p = 0; p < NPK; ++p) {
+      const int m = m0 + prow_k + p * 16;
+      const int iy = py[p] * a.sy + tdy, ix = px[p] * a.sx + tdx;
+      const bool in = m < m_end && x_col >= 0 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      const unsigned ox_ = in ? (unsigned)(((pb[p] * a.IH + iy) * a.IW + ix) * x_pixb + x_col) : OOB;
+      const u4 vx = __builtin_amdgcn_raw_buffer_load_b128(xr, ox_, 0, 0);
+      rx[p] = make_uint4(vx[0], vx[1], vx[2], vx[3]);
+      const int nx = px[p] + BP;
+      const int q = (int)(((unsigned)nx * a.mag_ow) >> 20);
+      px[p] = nx - q * a.OW;
+      const int ny = py[p] + q;
+      const int q2 = (int)(((unsigned)ny * a.mag_oh) >> 20);
+      py[p] = ny - q2 * a.OH;
+      pb[p] += q2;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    unsigned char* sd = smem_w + buf * (OPN + OPK);
+#pragma unroll
+    for (int p = 0; p < NPN; ++p) *(uint4*)(sd + (prow_n + p * 32) * ROWN + chunk_n * 16) = rdy[p];
+#pragma unroll
+    for (int p = 0; p < NPK; ++p) *(uint4*)(sd + OPN + (prow_k + p * 16) * ROWK + chunk_k * 16) = rx[p];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+  const int row_in = (grp >> 1) * 8 + q, col_in = ((grp & 1) * 16 + p4 * 4) * 2;
+  const int off_n = row_in * ROWN + col_in + wr * 128, off_k = row_in * ROWK + col_in + wc * 128;
+
+  const int nstage = (m_end - m_begin + BP - 1) / BP;
+  load_stage(m_begin);
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const bool more = s + 1 < nstage;
+    if (more) load_stage(m_begin + (s + 1) * BP);
+    const unsigned char* sd = smem_w + (s & 1) * (OPN + OPK);
+#pragma unroll
+    for (int ks = 0; ks < BP / 16; ++ks) {
+      s16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char* pa = sd + ks * 16 * ROWN + off_n + i * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWN));
+        fa[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned char* pbp = sd + OPN + ks * 16 * ROWK + off_k + j * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pbp);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pbp + 4 * ROWK));
+        fb[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma16<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) store_stage((s + 1) & 1);
+    __syncthreads();
+  }
+  const int fcol = lane & 31, fh = lane >> 5;
+  const bool interior = n0 + TN <= a.N && k0 + TK <= a.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int k = k0 + wc * 64 + j * 32 + fcol;
+        if (interior || (n < a.N && k < a.K)) { if (a.dw_split_stride) dw_out<true>(dwp + (long)n * a.K + k, acc[i][j][e]); else dw_out<false>(dwp + (long)n * a.K + k, acc[i][j][e]); }
+      }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3 stride-1: patch kernel (r03)
 // The GEMM kernels above fetch an input pixel once per TAP (the nine (tap, channel) column tiles are different workgroups or
 // different stages): 32-64 FLOP per byte through the CU's 64 B/clk address path, which is what bounds them.  Here a workgroup
@@ -602,21 +746,25 @@ static int cu_count() {
 // the 128-wide tile, 3 for the 64-wide); the pixel-split count is rounded DOWN so the grid never spills a nearly empty
 // extra round (1048 workgroups on 512 slots ran three rounds for two rounds of work).
 // kind 3 (16-bit, 3x3 stride 1 shapes of wgrad3x3p_ws): the patch kernel, one tap row per workgroup, r rounds of resident workgroups
+// kind 4 (16-bit): the wide tile, 128 filters x 256 columns, eight waves, one workgroup per CU
 constexpr int WGRAD_NCFG = SY11_WGRAD_NCFG;
-static_assert(WGRAD_NCFG == 16, "configuration table and its size (tune.h) out of step");
+static_assert(WGRAD_NCFG == 20, "configuration table and its size (tune.h) out of step");
+constexpr int WGRAD_WIDE_LDS = 2 * 64 * ((128 * 2 + 64) + (256 * 2 + 64));
 static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   const int kind = cfg >> 2;
   const bool psplit = kind == 2;
   const bool patch = kind == 3;
+  const bool wide = kind == 4;
+  if (wide && dtype == SY11_F32) SY11_FAIL(SY11_EUNSUPPORTED, "conv2d_wgrad: configuration %d is 16-bit only", cfg);
   const int patch_ws = patch ? wgrad3x3p_ws(a) : 0;
   if (patch && (!patch_ws || dtype == SY11_F32)) SY11_FAIL(SY11_EUNSUPPORTED, "conv2d_wgrad: configuration %d does not take this shape", cfg);
   const int patch_sp = patch ? wgrad3x3p_sp(a, patch_ws) : 0;
   const int tile = kind == 1 ? 128 : 64;
-  const int slots = cu_count() * (patch ? (patch_sp == 80 ? 4 : 2) : (tile == 128 ? 2 : 3));
+  const int slots = cu_count() * (wide ? 1 : patch ? (patch_sp == 80 ? 4 : 2) : (tile == 128 ? 2 : 3));
   const int target_wg = (slots << (cfg & 3)) >> 2;
   const int pcb = a.C > 32 ? 64 : 32, pnb = a.N > 32 ? 64 : 32;          // patch kernel: channels x filters per workgroup
-  a.tiles_k = patch ? cdiv(a.C, pcb) : cdiv(a.K, tile);
-  const int tiles = patch ? a.tiles_k * cdiv(a.N, pnb) * 3 : a.tiles_k * cdiv(a.N, tile);
+  a.tiles_k = patch ? cdiv(a.C, pcb) : cdiv(a.K, wide ? 256 : tile);
+  const int tiles = patch ? a.tiles_k * cdiv(a.N, pnb) * 3 : a.tiles_k * cdiv(a.N, wide ? 128 : tile);
   int splits = target_wg / tiles;
   const int stage_px = patch ? patch_sp : 64;
   const int max_splits = cdiv(a.M, 8 * stage_px);      // >= 8 stages per split
@@ -639,7 +787,17 @@ static int wgrad_launch_cfg(WgradArgs a, int dtype, hipStream_t st, int cfg) {
   a.mag_ow = (unsigned)(((1u << 20) + a.OW - 1) / a.OW);
   a.mag_oh = (unsigned)(((1u << 20) + a.OH - 1) / a.OH);
   dim3 grid(cdiv(a.total, 8) * 8), block(256);
-  if (dtype == SY11_F32) {
+  if (wide) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)wgrad16w_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_WIDE_LDS) != hipSuccess ||
+          hipFuncSetAttribute((const void*)wgrad16w_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_WIDE_LDS) != hipSuccess)
+        SY11_FAIL(SY11_ELAUNCH, "conv2d_wgrad: cannot raise the LDS limit to %d bytes", WGRAD_WIDE_LDS);
+      attr_set = true;
+    }
+    if (dtype == SY11_F16) hipLaunchKernelGGL((wgrad16w_kernel<_Float16>), grid, dim3(512), WGRAD_WIDE_LDS, st, a);
+    else hipLaunchKernelGGL((wgrad16w_kernel<__bf16>), grid, dim3(512), WGRAD_WIDE_LDS, st, a);
+  } else if (dtype == SY11_F32) {
     if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<float, 128>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<float, 64>), grid, block, 0, st, a);
   } else if (patch) {
@@ -724,7 +882,7 @@ extern "C" int sy11_conv2d_wgrad(const sy11_conv_desc* d, const void* x, const v
   if (d->dtype != SY11_F32 && a.M >= 200000 && wgrad3x3p_ws(a)) cfg = 14;
   const int forced = sy11_opt(OPT_WGRAD_CFG);
   const int ncfg = d->dtype == SY11_F32 ? 8 : WGRAD_NCFG;
-  auto patch_ok = [&](int c) { return c < 12 || wgrad3x3p_ws(a) != 0; };
+  auto patch_ok = [&](int c) { return c < 12 || (c < 16 ? wgrad3x3p_ws(a) != 0 : (a.N > 64 && a.K > 128)); };
   if (forced >= 0 && forced < ncfg && patch_ok(forced)) return wgrad_launch_cfg(a, d->dtype, st, forced);
   {                                  // a recorded / imported pick is honoured even with measuring off
     sy11tune::Cache& cache = sy11tune::cache(1);

@@ -182,7 +182,7 @@ def test_every_igemm_and_wgrad_tile_configuration(case):
             o.conv2d_dgrad(dyv, wt, dx, (B, OH, OW, N), k, s, p, accumulate=True)
             close(to_nchw(dx), 2 * ref_dx, dtype, f"dgrad accumulate cfg {cfg}", mult=2)
         _lib.set_option("igemm_cfg", -1)
-        for cfg in range(16):
+        for cfg in range(20):
             _lib.set_option("wgrad_cfg", cfg)
             dw = torch.zeros(N, k, k, Cn, dtype=torch.float32, device=DEV)
             o.conv2d_wgrad(xv, dyv, dw, k, s, p)
@@ -320,6 +320,35 @@ def test_patch_filter_gradient_bf16_and_slices(case):
             close(dw.cpu().permute(0, 3, 1, 2), ref, torch.float32, f"wgrad cfg {cfg}", mult=200)      # bf16 operands: 8 mantissa bits
             o.conv2d_wgrad(wide_x[..., 8:], wide_dy[..., :N], dw, 3, 1, 1)
             close(dw.cpu().permute(0, 3, 1, 2), 2 * ref, torch.float32, f"wgrad cfg {cfg} accumulate", mult=400)
+    finally:
+        _lib.set_option("wgrad_cfg", -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 256, 20, 20, 256, 3, 1), (1, 40, 23, 31, 136, 3, 2), (3, 384, 13, 17, 128, 1, 1), (2, 72, 16, 16, 200, 3, 1)])
+def test_wide_tile_filter_gradient(case, dtype):
+    """wgrad configurations 16-19 (wgrad16w_kernel, 128 filters x 256 columns, eight waves): whole and partial tiles in both
+    directions (N = 136, 200; K = 360, 384, 648), stride 2, operands that are channel slices of wider tensors; accumulates."""
+    from sy11 import _lib
+    o = ops()
+    B, Cn, H, W, N, k, s = case
+    p = k // 2
+    OH, OW = o.conv_out_hw(H, W, k, s, p)
+    x, dy = rnd(B, Cn, H, W, seed=61), rnd(B, N, OH, OW, seed=62)
+    ref = torch.nn.grad.conv2d_weight(q(x, dtype), (N, Cn, k, k), q(dy, dtype), s, p)
+    wide_x = torch.zeros(B, H, W, Cn + 8, dtype=dtype, device=DEV)
+    wide_x[..., 8:] = nhwc(x, dtype)
+    wide_dy = torch.zeros(B, OH, OW, N + 16, dtype=dtype, device=DEV)
+    wide_dy[..., :N] = nhwc(dy, dtype)
+    mult = 200 if dtype == torch.bfloat16 else 8
+    try:
+        for cfg in range(16, 20):
+            _lib.set_option("wgrad_cfg", cfg)
+            dw = torch.zeros(N, k, k, Cn, dtype=torch.float32, device=DEV)
+            o.conv2d_wgrad(wide_x[..., 8:], wide_dy[..., :N], dw, k, s, p)
+            close(dw.cpu().permute(0, 3, 1, 2), ref, torch.float32, f"wgrad cfg {cfg}", mult=mult)
+            o.conv2d_wgrad(wide_x[..., 8:], wide_dy[..., :N], dw, k, s, p)
+            close(dw.cpu().permute(0, 3, 1, 2), 2 * ref, torch.float32, f"wgrad cfg {cfg} accumulate", mult=2 * mult)
     finally:
         _lib.set_option("wgrad_cfg", -1)
 

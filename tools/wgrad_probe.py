@@ -22,11 +22,11 @@ def main():
         dw = torch.zeros(N, 3, 3, C, device="cuda")
         gf = 2.0 * B * H * W * N * C * 9 / 1e9
         res = {}
-        for cfg in range(16):
+        for cfg in range(20):
             _lib.set_option("wgrad_cfg", cfg)
             res[cfg] = timed(lambda: ops.conv2d_wgrad(x, dy, dw, 3, 1, 1), 10, False)
         _lib.set_option("wgrad_cfg", -1)
-        bo = min(range(12), key=lambda c: res[c])
+        bo = min([c for c in range(12)], key=lambda c: res[c])
         bn = min(range(12, 16), key=lambda c: res[c])
         tot_old += res[bo] * cnt
         tot_new += min(res[bo], res[bn]) * cnt
