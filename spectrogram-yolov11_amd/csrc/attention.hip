@@ -8,17 +8,21 @@
 #include "common.h"
 
 #define ATT_QT 32
+constexpr size_t ATT_LDS_MAX = 160 * 1024;     // score rows (QT x N f32) stay in LDS up to here
 
-template <typename T>
+// GS (r04): the QT x N score rows live in the workgroup's own rows of P (global; same [row][N] layout) instead of LDS — the path for
+// token counts whose rows do not fit 160 KB (f32 at N > ~1 200; the 16-bit MFMA kernels never hold score rows).  Rows past N are
+// never touched in that form.
+template <typename T, bool GS = false>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(int B, int N, int heads, int kd, int hd, const T* __restrict__ qkv, int qkv_ld,
                                                             T* __restrict__ o, int o_ld, float* __restrict__ p, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* sS = sm;                       // [QT][N]
-  float* sQ = sS + ATT_QT * N;          // [QT][kd]
-  float* sK = sQ + ATT_QT * kd;         // [64][kd+1]
   const int tid = threadIdx.x;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int q0 = qt * ATT_QT;
+  float* sS = GS ? p + (((long)b * heads + h) * N + q0) * N : sm;       // [QT][N]
+  float* sQ = GS ? sm : sm + ATT_QT * N;                                 // [QT][kd]
+  float* sK = sQ + ATT_QT * kd;                                          // [64][kd+1]
   const int hc = 2 * kd + hd;
   const T* base = qkv + (long)b * N * qkv_ld + h * hc;
   for (int i = tid; i < ATT_QT * kd; i += 256) {
@@ -37,6 +41,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(int B, int N, int he
 #pragma unroll
       for (int qq = 0; qq < ATT_QT / 4; ++qq) {
         const int qi = qg * (ATT_QT / 4) + qq;
+        if (GS && q0 + qi >= N) continue;
         float s = 0.f;
         for (int d = 0; d < kd; ++d) s += sQ[qi * kd + d] * sK[j * (kd + 1) + d];
         sS[qi * N + j0 + j] = s;
@@ -47,12 +52,14 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(int B, int N, int he
   // softmax: 8 lanes per query row
   {
     const int qi = tid >> 3, l = tid & 7;
+    const bool live = q0 + qi < N;
+    const int n_row = (GS && !live) ? 0 : N;                 // global rows past N do not exist
     float mx = -INFINITY;
-    for (int j = l; j < N; j += 8) mx = fmaxf(mx, sS[qi * N + j]);
+    for (int j = l; j < n_row; j += 8) mx = fmaxf(mx, sS[qi * N + j]);
 #pragma unroll
     for (int o_ = 4; o_ >= 1; o_ >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o_));
     float sum = 0.f;
-    for (int j = l; j < N; j += 8) {
+    for (int j = l; j < n_row; j += 8) {
       const float e = __expf(sS[qi * N + j] - mx);
       sS[qi * N + j] = e;
       sum += e;
@@ -60,12 +67,11 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(int B, int N, int he
 #pragma unroll
     for (int o_ = 4; o_ >= 1; o_ >>= 1) sum += __shfl_xor(sum, o_);
     const float inv = 1.f / sum;
-    const bool live = q0 + qi < N;
     float* prow = p + (((long)b * heads + h) * N + (q0 + qi)) * N;
-    for (int j = l; j < N; j += 8) {
+    for (int j = l; j < n_row; j += 8) {
       const float v = sS[qi * N + j] * inv;
       sS[qi * N + j] = v;
-      if (live) prow[j] = v;
+      if (!GS && live) prow[j] = v;
     }
   }
   __syncthreads();
@@ -81,16 +87,16 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(int B, int N, int he
 }
 
 // backward A: per query tile.  dP = dO v^T, delta_i = sum_j dP P, dS = P (dP - delta) -> ws;  dq = scale * dS k
-template <typename T>
+template <typename T, bool GS = false>
 __global__ __launch_bounds__(256) void attention_bwd_q_kernel(int B, int N, int heads, int kd, int hd, const T* __restrict__ qkv, int qkv_ld,
                                                               const float* __restrict__ p, const T* __restrict__ d_o, int do_ld,
                                                               T* __restrict__ dqkv, int dqkv_ld, float* __restrict__ ds, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* sS = sm;                        // [QT][N] dP then dS
-  float* sO = sS + ATT_QT * N;           // [QT][hd] dO tile
   const int tid = threadIdx.x;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int q0 = qt * ATT_QT;
+  float* sS = GS ? ds + (((long)b * heads + h) * N + q0) * N : sm;       // [QT][N] dP then dS (GS: the workgroup's own rows of the dS workspace)
+  float* sO = GS ? sm : sm + ATT_QT * N;                                  // [QT][hd] dO tile
   const int hc = 2 * kd + hd;
   const T* base = qkv + (long)b * N * qkv_ld + h * hc;
   for (int i = tid; i < ATT_QT * hd; i += 256) {
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(int B, int N, int 
     sO[i] = (q0 + qi < N) ? ElemTraits<T>::to_f(d_o[((long)b * N + q0 + qi) * do_ld + h * hd + e]) : 0.f;
   }
   __syncthreads();
-  for (int idx = tid; idx < ATT_QT * N; idx += 256) {
+  for (int idx = tid; idx < (GS ? min(ATT_QT, N - q0) : ATT_QT) * N; idx += 256) {
     const int qi = idx / N, j = idx - qi * N;
     float s = 0.f;
     const T* vp = base + (long)j * qkv_ld + 2 * kd;
@@ -116,9 +122,10 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(int B, int N, int 
     for (int o_ = 4; o_ >= 1; o_ >>= 1) dl += __shfl_xor(dl, o_);
     float* dsrow = ds + (((long)b * heads + h) * N + (q0 + qi)) * N;
     for (int j = l; j < N; j += 8) {
+      if (GS && !live) break;
       const float v = live ? prow[j] * (sS[qi * N + j] - dl) : 0.f;
       sS[qi * N + j] = v;
-      if (live) dsrow[j] = v;
+      if (!GS && live) dsrow[j] = v;
     }
   }
   __syncthreads();
@@ -234,12 +241,14 @@ __global__ __launch_bounds__(256) void attention_fwd_fast(int B, int N, int head
   __syncthreads();
   {
     const int qi = tid >> 3, l = tid & 7;
+    const bool live = q0 + qi < N;
+    const int n_row = N;
     float mx = -INFINITY;
-    for (int j = l; j < N; j += 8) mx = fmaxf(mx, sS[qi * N + j]);
+    for (int j = l; j < n_row; j += 8) mx = fmaxf(mx, sS[qi * N + j]);
 #pragma unroll
     for (int o_ = 4; o_ >= 1; o_ >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o_));
     float sum = 0.f;
-    for (int j = l; j < N; j += 8) {
+    for (int j = l; j < n_row; j += 8) {
       const float e = __expf(sS[qi * N + j] - mx);
       sS[qi * N + j] = e;
       sum += e;
@@ -247,9 +256,8 @@ __global__ __launch_bounds__(256) void attention_fwd_fast(int B, int N, int head
 #pragma unroll
     for (int o_ = 4; o_ >= 1; o_ >>= 1) sum += __shfl_xor(sum, o_);
     const float inv = 1.f / sum;
-    const bool live = q0 + qi < N;
     float* prow = p + (((long)b * heads + h) * N + (q0 + qi)) * N;
-    for (int j = l; j < N; j += 8) {
+    for (int j = l; j < n_row; j += 8) {
       const float v = sS[qi * N + j] * inv;
       sS[qi * N + j] = v;
       if (live) prow[j] = v;
@@ -796,10 +804,7 @@ static int att_check(int dtype, int B, int N, int heads, int kd, int hd, const c
   SY11_REQUIRE(dtype_ok(dtype) && B > 0 && N > 0 && heads > 0 && kd > 0 && hd > 0, "%s: bad dims", who);
   SY11_REQUIRE(kd <= 64 && hd <= 128 && 32 * (kd + hd) <= 16 * 256, "%s: kd<=64, hd<=128 supported", who);
   SY11_REQUIRE(heads <= 65535 && B <= 65535, "%s: heads/B exceed grid limits", who);
-  if (!mma) {                                    // the VALU kernels keep 32 score rows of N floats in LDS; the MFMA path does not
-    const size_t lds = (size_t)(ATT_QT * N + ATT_QT * (kd > hd ? kd : hd) + 64 * ((kd > hd ? kd : hd) + 1)) * 4;
-    SY11_REQUIRE(lds <= 160 * 1024, "%s: N=%d needs %zu bytes of LDS (>160 KiB)", who, N, lds);
-  }
+  (void)mma;                                     // every path takes any N: the VALU kernels keep their score rows in LDS while they fit, else in P / dS
   return SY11_OK;
 }
 
@@ -817,6 +822,14 @@ extern "C" int sy11_attention_fwd(int32_t dtype, int32_t B, int32_t N, int32_t h
     dim3 gm(cdiv(cdiv(N, 32), 4), heads, B);
     SY11_DISPATCH_DTYPE(dtype, T, {
       hipLaunchKernelGGL((attention_fwd_mma<T>), gm, block, 0, st, B, N, heads, (const T*)qkv, qkv_ld, (T*)o, o_ld, p, scale);
+    });
+    SY11_LAUNCH_CHECK("attention_fwd");
+    return SY11_OK;
+  }
+  if ((size_t)(ATT_QT * N + ATT_QT * 32 + 64 * 64) * 4 > ATT_LDS_MAX || lds > ATT_LDS_MAX) {     // score rows beyond LDS: keep them in the workgroup's rows of P
+    const size_t lg = (size_t)(ATT_QT * kd + 64 * (kd + 1)) * 4;
+    SY11_DISPATCH_DTYPE(dtype, T, {
+      hipLaunchKernelGGL((attention_fwd_kernel<T, true>), grid, block, lg, st, B, N, heads, kd, hd, (const T*)qkv, qkv_ld, (T*)o, o_ld, p, scale);
     });
     SY11_LAUNCH_CHECK("attention_fwd");
     return SY11_OK;
@@ -864,6 +877,15 @@ extern "C" int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t h
       if (lk > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_bwd_kv_mma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lk);
       hipLaunchKernelGGL((attention_bwd_q_mma<T>), gm, block, lq, st, B, N, heads, (const T*)qkv, qkv_ld, p, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, workspace, scale);
       hipLaunchKernelGGL((attention_bwd_kv_mma<T>), gm, block, lk, st, B, N, heads, (const T*)qkv, qkv_ld, p, (const float*)workspace, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, scale);
+    });
+    SY11_LAUNCH_CHECK("attention_bwd");
+    return SY11_OK;
+  }
+  if ((size_t)(ATT_QT * N + ATT_QT * 64 + 64 * 65) * 4 > ATT_LDS_MAX || lds > ATT_LDS_MAX) {     // dP / dS rows beyond LDS: in the dS workspace
+    const size_t lg = (size_t)(ATT_QT * hd) * 4;
+    SY11_DISPATCH_DTYPE(dtype, T, {
+      hipLaunchKernelGGL((attention_bwd_q_kernel<T, true>), gq, block, lg, st, B, N, heads, kd, hd, (const T*)qkv, qkv_ld, p, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, workspace, scale);
+      hipLaunchKernelGGL((attention_bwd_kv_kernel<T>), gk, block, 0, st, B, N, heads, kd, hd, (const T*)qkv, qkv_ld, p, (const float*)workspace, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, scale);
     });
     SY11_LAUNCH_CHECK("attention_bwd");
     return SY11_OK;

@@ -86,29 +86,33 @@ class LetterBox:
         self.center = center
         self.device = device
 
+    @staticmethod
+    def _border(total, centred):
+        """Border pixels before / after the image along one axis.  Centred: half each, rounded apart by -/+ 0.1 exactly as
+        augment.py:1576-1577 does (an odd total puts its extra pixel after the image); else everything after it."""
+        if not centred:
+            return 0, int(round(total + 0.1))
+        half = total / 2
+        return int(round(half - 0.1)), int(round(half + 0.1))
+
     def geometry(self, shape, new_shape=None):
         """augment.py:1551-1580 — (new_unpad (w, h), ratio (w, h), top, bottom, left, right) for a (h, w) image."""
-        new_shape = self.new_shape if new_shape is None else new_shape
-        if isinstance(new_shape, int):
-            new_shape = (new_shape, new_shape)
-        r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+        target = self.new_shape if new_shape is None else new_shape
+        th, tw = (target, target) if isinstance(target, int) else (target[0], target[1])
+        h, w = shape[0], shape[1]
+        gain = min(th / h, tw / w)
         if not self.scaleup:
-            r = min(r, 1.0)
-        ratio = r, r
-        new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
-        dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
-        if self.auto:
-            dw, dh = np.mod(dw, self.stride), np.mod(dh, self.stride)
-        elif self.scaleFill:
-            dw, dh = 0.0, 0.0
-            new_unpad = (new_shape[1], new_shape[0])
-            ratio = new_shape[1] / shape[1], new_shape[0] / shape[0]
-        if self.center:
-            dw /= 2
-            dh /= 2
-        top, bottom = int(round(dh - 0.1)) if self.center else 0, int(round(dh + 0.1))
-        left, right = int(round(dw - 0.1)) if self.center else 0, int(round(dw + 0.1))
-        return new_unpad, ratio, top, bottom, left, right
+            gain = min(gain, 1.0)
+        if self.scaleFill and not self.auto:                  # stretch to the target: no border, per-axis ratios
+            inner, ratio, pad_w, pad_h = (tw, th), (tw / w, th / h), 0.0, 0.0
+        else:
+            inner, ratio = (int(round(w * gain)), int(round(h * gain))), (gain, gain)
+            pad_w, pad_h = tw - inner[0], th - inner[1]
+            if self.auto:                                     # minimum rectangle: only up to the next stride multiple
+                pad_w, pad_h = pad_w % self.stride, pad_h % self.stride
+        top, bottom = self._border(pad_h, self.center)
+        left, right = self._border(pad_w, self.center)
+        return inner, ratio, top, bottom, left, right
 
     def into(self, image, dst, new_shape=None, reverse_c=True):
         """Letterbox ``image`` straight into ``dst`` — one (3, H, W) slot of a batch tensor, uint8 or float (/255, with
@@ -185,25 +189,20 @@ class Format:
         self.defer = defer                     # keep a DeviceImage unrendered: collate_fn renders it into its batch slot
 
     def __call__(self, labels):
-        img = labels.pop("img")
+        img, cls, inst = labels.pop("img"), labels.pop("cls"), labels.pop("instances")
         h, w = img.shape[:2]
-        cls = labels.pop("cls")
-        instances = labels.pop("instances")
-        instances.convert_bbox(format=self.bbox_format)
-        instances.denormalize(w, h)
-        nl = len(instances)
-        labels["img"] = self._format_img(img)
-        labels["cls"] = torch.from_numpy(cls) if nl else torch.zeros(nl)
-        if nl:
-            b = instances.bboxes
-            if self.normalize:                 # the same float32 divisions as the reference's tensor `/=`, done before wrapping
-                b[:, [0, 2]] /= np.float32(w)
-                b[:, [1, 3]] /= np.float32(h)
-            labels["bboxes"] = torch.from_numpy(b)
-        else:
-            labels["bboxes"] = torch.zeros((nl, 4))
+        inst.convert_bbox(format=self.bbox_format)
+        inst.denormalize(w, h)
+        n = len(inst)
+        boxes = inst.bboxes if n else np.zeros((0, 4), np.float32)
+        if n and self.normalize:               # the same float32 divisions as the reference's tensor `/=`, done before wrapping
+            boxes[:, 0::2] /= np.float32(w)
+            boxes[:, 1::2] /= np.float32(h)
+        out = {"img": self._format_img(img), "cls": torch.from_numpy(cls) if n else torch.zeros(0),
+               "bboxes": torch.from_numpy(boxes) if n else torch.zeros((0, 4))}
         if self.batch_idx:
-            labels["batch_idx"] = torch.zeros(nl)
+            out["batch_idx"] = torch.zeros(n)          # collate_fn adds the image's index in its batch
+        labels.update(out)
         return labels
 
     def _format_img(self, img):

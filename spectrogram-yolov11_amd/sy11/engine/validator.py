@@ -58,51 +58,49 @@ class DetectionValidator:
         return ops.non_max_suppression(preds, self.args["conf"], self.args["iou"], nc=self.nc, multi_label=True,
                                        agnostic=self.args["single_cls"] or self.args["agnostic_nms"], max_det=self.args["max_det"])
 
-    # ---- val.py:108-128
+    # ---- val.py:108-128: one image's labels, mapped back to the image as it was before LetterBox
+    def _image_geometry(self, si, batch):
+        net_hw = tuple(batch["img"].shape[2:])
+        native_hw = batch["ori_shape"][si] if "ori_shape" in batch else net_hw
+        return net_hw, native_hw, (batch["ratio_pad"][si] if "ratio_pad" in batch else None)
+
     def _prepare_batch(self, si, batch):
-        idx = batch["batch_idx"] == si
-        cls = batch["cls"][idx].squeeze(-1)
-        bbox = batch["bboxes"][idx]
-        imgsz = tuple(batch["img"].shape[2:])
-        ori_shape = batch["ori_shape"][si] if "ori_shape" in batch else imgsz
-        ratio_pad = batch["ratio_pad"][si] if "ratio_pad" in batch else None
-        if len(cls):
-            bbox = ops.xywh2xyxy(bbox) * torch.tensor(imgsz, device=bbox.device)[[1, 0, 1, 0]]
-            ops.scale_boxes(imgsz, bbox, ori_shape, ratio_pad=ratio_pad)          # labels to native image space
-        return {"cls": cls, "bbox": bbox, "ori_shape": ori_shape, "imgsz": imgsz, "ratio_pad": ratio_pad}
+        net_hw, native_hw, ratio_pad = self._image_geometry(si, batch)
+        mine = batch["batch_idx"] == si
+        cls, box = batch["cls"][mine].squeeze(-1), batch["bboxes"][mine]
+        if cls.numel():
+            h, w = net_hw
+            box = ops.xywh2xyxy(box) * box.new_tensor([w, h, w, h])             # normalised -> network-input pixels
+            ops.scale_boxes(net_hw, box, native_hw, ratio_pad=ratio_pad)        # -> native pixels (in place)
+        return {"cls": cls, "bbox": box, "ori_shape": native_hw, "imgsz": net_hw, "ratio_pad": ratio_pad}
 
     def _prepare_pred(self, pred, pbatch):
-        predn = pred.clone()
-        ops.scale_boxes(pbatch["imgsz"], predn[:, :4], pbatch["ori_shape"], ratio_pad=pbatch["ratio_pad"])
-        return predn
+        native = pred.clone()
+        ops.scale_boxes(pbatch["imgsz"], native[:, :4], pbatch["ori_shape"], ratio_pad=pbatch["ratio_pad"])
+        return native
+
+    def _record(self, conf, pred_cls, tp, target_cls):
+        """One image's contribution to the running statistics (the five lists get_stats concatenates)."""
+        for key, val in (("conf", conf), ("pred_cls", pred_cls), ("tp", tp), ("target_cls", target_cls), ("target_img", target_cls.unique())):
+            self.stats[key].append(val)
 
     # ---- val.py:130-175
     def update_metrics(self, preds, batch):
-        for si, pred in enumerate(preds):
+        for si, det in enumerate(preds):
             self.seen += 1
-            npr = len(pred)
-            dev = pred.device
-            stat = dict(conf=torch.zeros(0, device=dev), pred_cls=torch.zeros(0, device=dev),
-                        tp=torch.zeros(npr, self.niou, dtype=torch.bool, device=dev))
-            pbatch = self._prepare_batch(si, batch)
-            cls, bbox = pbatch.pop("cls"), pbatch.pop("bbox")
-            nl = len(cls)
-            stat["target_cls"] = cls
-            stat["target_img"] = cls.unique()
-            if npr == 0:
-                if nl:
-                    for k in self.stats:
-                        self.stats[k].append(stat[k])
+            labels = self._prepare_batch(si, batch)
+            gt_cls, gt_box = labels["cls"], labels["bbox"]
+            if det.shape[0] == 0:
+                if gt_cls.numel():                                   # missed labels still count as targets; an empty image adds nothing
+                    none = torch.zeros(0, device=det.device)
+                    self._record(none, none, torch.zeros(0, self.niou, dtype=torch.bool, device=det.device), gt_cls)
                 continue
             if self.args["single_cls"]:
-                pred[:, 5] = 0
-            predn = self._prepare_pred(pred, pbatch)
-            stat["conf"] = predn[:, 4]
-            stat["pred_cls"] = predn[:, 5]
-            if nl:
-                stat["tp"] = self._process_batch(predn, bbox, cls)
-            for k in self.stats:
-                self.stats[k].append(stat[k])
+                det[:, 5] = 0
+            native = self._prepare_pred(det, labels)
+            tp = (self._process_batch(native, gt_box, gt_cls) if gt_cls.numel()
+                  else torch.zeros(det.shape[0], self.niou, dtype=torch.bool, device=det.device))
+            self._record(native[:, 4], native[:, 5], tp, gt_cls)
 
     # ---- val.py:205-232
     def _process_batch(self, detections, gt_bboxes, gt_cls):
