@@ -233,17 +233,18 @@ template <int CTRL> __device__ __forceinline__ float quad_bcast(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
-__global__ __launch_bounds__(256) void stft_logmel1024w_kernel(int L, int n_frames, int n_mel, int run, const float2* __restrict__ iq,
+template <int WAVES, int MINB, int MELU>
+__global__ __launch_bounds__(WAVES * 64, MINB) void stft_logmel1024w_kernel(int L, int n_frames, int n_mel, int run, const float2* __restrict__ iq,
                                                                const float* __restrict__ window, const int* __restrict__ mel_start,
                                                                const float* __restrict__ mel_w, float* __restrict__ db, float* __restrict__ minmax) {
   constexpr int N = 1024, EXS = 68;                         // exchange row stride in float2 (544 B: a quad's 32 bytes land 8 banks apart)
   __shared__ float2 s_twA[16 * 64];                         // [k1][n'] = W_1024^{n' k1}
   __shared__ float2 s_twB[4 * 16];                          // [c][p]   = W_64^{c p}
-  __shared__ __attribute__((aligned(16))) float s_ex[4][16 * EXS * 2];   // per wave: the exchange image, then the padded power spectrum
-  __shared__ float rmin[4], rmax[4];
+  __shared__ __attribute__((aligned(16))) float s_ex[WAVES][16 * EXS * 2];   // per wave: the exchange image, then the padded power spectrum
+  __shared__ float rmin[WAVES], rmax[WAVES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
-  for (int i = tid; i < 1024; i += 256) {
+  for (int i = tid; i < 1024; i += WAVES * 64) {
     float sn, cs;
     sincospif(-2.0f * (float)((i & 63) * (i >> 6)) / 1024.0f, &sn, &cs);
     s_twA[i] = make_float2(cs, sn);
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void stft_logmel1024w_kernel(int L, int n_fram
   float2* ex = (float2*)s_ex[wave];
   float* pw = s_ex[wave];
   float lmin = INFINITY, lmax = -INFINITY;
-  const int f0 = (blockIdx.x * 4 + wave) * run;
+  const int f0 = (blockIdx.x * WAVES + wave) * run;
   float2 raw[16];
   if (f0 < n_frames) {
     const float2* src = iq + (long)b * L + (long)f0 * 256;
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void stft_logmel1024w_kernel(int L, int n_fram
     if (qo == 2 && k1 < 8) pw[N + k1] = pwr[0];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float* o = db + ((long)b * n_frames + frame) * n_mel;
-#pragma unroll 5
+#pragma unroll MELU
     for (int j = lane; j < n_mel; j += 64) {
       const int k0 = mel_start[j];
       const int s0 = k0 & (N - 1);                           // the image is already shifted: shifted bin k0 IS word k0
@@ -336,7 +337,9 @@ __global__ __launch_bounds__(256) void stft_logmel1024w_kernel(int L, int n_fram
   if (lane == 0) { rmin[wave] = lmin; rmax[wave] = lmax; }
   __syncthreads();
   if (tid == 0) {
-    const float mn = fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3])), mx = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+    float mn = rmin[0], mx = rmax[0];
+#pragma unroll
+    for (int i = 1; i < WAVES; ++i) { mn = fminf(mn, rmin[i]); mx = fmaxf(mx, rmax[i]); }
     if (mn <= mx) {                                          // a workgroup past the last frame contributes nothing
       atomic_min_f(minmax + 2 * b, mn);
       atomic_max_f(minmax + 2 * b + 1, mx);
@@ -399,7 +402,9 @@ extern "C" int sy11_stft_logmel(int32_t B, int32_t L, int32_t n_fft, int32_t hop
   if (n_fft == 1024 && hop == 256 && mel_taps == 8 && wave_fft && !radix2 && ((uintptr_t)mel_w & 15) == 0) {
     // one wave per frame, `run` consecutive frames per wave (shared samples stay in registers): 5 keeps 2 048 workgroups for 64 x 640 frames
     const int run = n_frames >= 320 ? 5 : (n_frames >= 16 ? 2 : 1);
-    hipLaunchKernelGGL(stft_logmel1024w_kernel, dim3(cdiv(n_frames, 4 * run), B), dim3(256), 0, st, L, n_frames, n_mel, run, (const float2*)iq, window,
+    // 3 waves per SIMD (r04): the register allocator's free choice is 170 VGPRs = 2 waves per SIMD; bounded to 168 the kernel keeps a third
+    // wave to cover the LDS exchanges (130 -> 116 us).  128 VGPRs (4 waves) spills 74 registers and loses (169 us); 8-wave workgroups change nothing.
+    hipLaunchKernelGGL((stft_logmel1024w_kernel<4, 3, 5>), dim3(cdiv(n_frames, 4 * run), B), dim3(256), 0, st, L, n_frames, n_mel, run, (const float2*)iq, window,
                        mel_start, mel_w, db, minmax);
     SY11_LAUNCH_CHECK("stft_logmel");
     return SY11_OK;
