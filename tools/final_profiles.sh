@@ -1,0 +1,12 @@
+set -e
+mkdir -p gpurun_out/r7f
+timeout -k 10 900 python -m pytest tests -q -m gpu -x > gpurun_out/r7f/gpu_suite.txt 2>&1 || { tail -30 gpurun_out/r7f/gpu_suite.txt; exit 1; }
+tail -3 gpurun_out/r7f/gpu_suite.txt
+SY11_WGRAD_STREAM=0 bash tools/prof_bench.sh stats r4ser > /dev/null
+python tools/trace_summary.py gpurun_out/prof_r4ser/run_kernel_trace.csv gpurun_out/r7f/z_serial 5 | tail -12
+cp gpurun_out/prof_r4ser/bench.json gpurun_out/r7f/z_serial_bench.json
+bash tools/prof_bench.sh stats r4fin > /dev/null
+python tools/trace_summary.py gpurun_out/prof_r4fin/run_kernel_trace.csv gpurun_out/r7f/z_final 5 | tail -12
+cp gpurun_out/prof_r4fin/bench.json gpurun_out/r7f/z_final_bench.json
+rm -f gpurun_out/prof_r4ser/run_kernel_trace.csv gpurun_out/prof_r4fin/run_kernel_trace.csv
+echo stats done
