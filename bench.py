@@ -56,7 +56,7 @@ def kernel_source_sha16():
 # kernel family -> the C-ABI entry points that launch it, and the kernel symbols a rocprofv3 trace shows for it
 FAMILIES = {
     "conv fwd+dgrad (dense)": {"calls": ("sy11_conv2d_fwd", "sy11_conv2d_dgrad"), "symbols": ("igemm_kernel", "igemm8_kernel", "igemm1x1p_kernel", "halo3x3_kernel", "halo_dgrad_s2_kernel", "smallc3x3_kernel")},
-    "conv wgrad (dense)": {"calls": ("sy11_conv2d_wgrad",), "symbols": ("wgrad16_kernel", "wgrad3x3p_kernel", "wgrad_kernel")},
+    "conv wgrad (dense)": {"calls": ("sy11_conv2d_wgrad",), "symbols": ("wgrad16_kernel", "wgrad16w_kernel", "wgrad3x3p_kernel", "wgrad_kernel")},
     "depthwise conv": {"calls": (), "symbols": ("dw3x3_kernel", "dwconv_")},
     "batchnorm": {"calls": ("sy11_bn_act_fwd", "sy11_bn_act_bwd_reduce", "sy11_bn_act_bwd_apply", "sy11_bn_act_bwd_apply_res", "sy11_bn_finalize"),
                   "symbols": ("bn_act_fwd_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "bn_finalize_kernel")},

@@ -10,3 +10,11 @@ python tools/trace_summary.py gpurun_out/prof_r4fin/run_kernel_trace.csv gpurun_
 cp gpurun_out/prof_r4fin/bench.json gpurun_out/r7f/z_final_bench.json
 rm -f gpurun_out/prof_r4ser/run_kernel_trace.csv gpurun_out/prof_r4fin/run_kernel_trace.csv
 echo stats done
+bash tools/prof_bench.sh pmc r4pmc > /dev/null
+python tools/pmc_summary.py gpurun_out/prof_r4pmc gpurun_out/r7f 2 | tail -12
+rm -rf gpurun_out/prof_r4pmc/FETCH_SIZE gpurun_out/prof_r4pmc/WRITE_SIZE
+bash tools/prof_bench.sh predict r4pred > /dev/null
+cp gpurun_out/prof_r4pred/bench.json gpurun_out/r7f/predict_val_bench.json
+f=$(ls gpurun_out/prof_r4pred/*kernel_stats.csv | head -1); cp "$f" gpurun_out/r7f/predict_val_kernel_stats.csv
+rm -f gpurun_out/prof_r4pred/*kernel_trace.csv
+echo all done
