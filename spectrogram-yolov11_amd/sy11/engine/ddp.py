@@ -16,12 +16,24 @@ import torch.distributed as dist
 from . import GradStore, module_post_backward
 
 
+# One-rank rehearsal (SY11_DDP_REHEARSE=1): every collective of the data-parallel path — parameter broadcast, tuner-pick broadcast,
+# the control group's flag, the flat-gradient all-reduce in both flavours — goes through the backend with world size 1 instead of being
+# skipped.  On a one-GPU box that is the only way RCCL itself (communicator set-up, its stream beside the replayed graphs) ever runs;
+# a sum over one rank is the identity, so the run must reproduce the single-process trainer bit for bit (tests/test_ddp_nccl_gpu.py).
+REHEARSE = os.environ.get("SY11_DDP_REHEARSE", "0") != "0"
+
+
+def active(group=None) -> bool:
+    """True when the collectives are to be issued: a process group of more than one rank (or the one-rank rehearsal)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or REHEARSE)
+
+
 def setup_process_group(backend: str | None = None):
     """init_process_group from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); 'nccl' IS RCCL on ROCm."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or REHEARSE) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -33,15 +45,16 @@ def setup_process_group(backend: str | None = None):
 
 def allreduce_flat(flat: torch.Tensor, group=None):
     """In-place SUM all-reduce of a flat gradient buffer (any backend)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
 
-# The two-bucket overlap below has only ever run over gloo (both ranks on one GPU, tests/test_ddp_gpu.py) — there the collective
-# does not run on its own device stream, so the concurrent case (RCCL reducing the `late` ranges while the second backward graph
-# replays) is UNVERIFIED on hardware.  Until a >= 2-GPU RCCL run of tests/test_ddp_nccl_gpu.py has been recorded it is opt-in
-# (SY11_DDP_OVERLAP=1); the default is ONE all-reduce of the flat buffer after backward: 37.8 MB over xGMI ~ 0.3 ms of a ~22 ms step.
+# The two-bucket overlap below has run over gloo with two ranks on one GPU (tests/test_ddp_gpu.py: the collective does not run on a
+# device stream of its own there) and over RCCL with ONE rank (r04, the rehearsal above: RCCL's stream beside the second backward
+# graph, bit-identical to the single-process trainer) — a >= 2-GPU RCCL run of tests/test_ddp_nccl_gpu.py's two-rank test has still not
+# been recorded, so it stays opt-in (SY11_DDP_OVERLAP=1); the default is ONE all-reduce of the flat buffer after backward: 37.8 MB
+# over xGMI ~ 0.3 ms of a ~19 ms step.
 OVERLAP = os.environ.get("SY11_DDP_OVERLAP", "0") != "0"
 BUCKET_LAYER = 5      # layers >= 5 of the yolo11 graph hold > 99 % of the parameters; layers 0-4 (320^2 ... 80^2 maps) a third of the backward time
 
@@ -104,7 +117,7 @@ class _StagedAllReduce:
             return
         if stage == 0:
             self.works, self.stage0_done = [], False                  # a backward that raised between the stages leaves nothing behind
-            if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            if not active(self.group):
                 return
             self._ranges()
             if not self.late or not self.early:
@@ -153,7 +166,7 @@ def share_tuner_picks(src: int = 0, group=None):
     """Every rank runs the kernels rank ``src`` measured: the tile autotuner's pick tables go from ``src`` to everybody
     (libsy11 sy11_tune_export / sy11_tune_import).  Collective: call on all ranks.  Returns the number of picks."""
     from .. import _lib
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not active(group):
         return len(_lib.tune_export()) // 16
     box = [_lib.tune_export() if dist.get_rank(group) == src else None]
     dist.broadcast_object_list(box, src, group=group)
@@ -171,7 +184,7 @@ def control_group():
     A collective on it blocks only the host thread — which runs a step ahead of the GPU — never the launch stream, and needs no
     device synchronisation to read its result.  Collective: created on first use by all ranks together."""
     global _CTL_GROUP
-    if not dist.is_initialized() or dist.get_world_size() <= 1:
+    if not active():
         return None
     if _CTL_GROUP is None:
         _CTL_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
@@ -235,7 +248,7 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
     """Rank-0 weights and buffers to everybody (what DDP's constructor does).  With a flat layout (engine/flat.py) that is two
     broadcasts of the flat buffers plus the few tensors living outside them; otherwise one per tensor (through a contiguous
     staging copy when a backend cannot take the tensor's strides)."""
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not active(group):
         return
     flat = model.__dict__.get("_sy11_flat")
     covered = []

@@ -30,6 +30,7 @@ class DetectionTrainer:
         self.model.args = self.args                       # v8DetectionLoss reads box / cls / dfl gains here
         self.batch_size = batch_size
         self.world_size = world_size
+        self.data_parallel = world_size > 1 or ddp.REHEARSE     # issue the collectives (world size 1 only in the one-rank rehearsal)
         self.producer = producer                           # optional IQ -> image producer (SpectrogramProducer)
         self.amp = bool(self.args.amp)
         if self.args.deterministic is not None and self.device.type == "cuda":
@@ -58,7 +59,7 @@ class DetectionTrainer:
             store.begin_backward(self.device)
             self.model.__dict__["_sy11_grads"] = store
             self.model.__dict__["_sy11_flat"] = self.flat
-            if world_size > 1:                               # DDP's constructor: rank-0 weights and buffers to everybody (two
+            if self.data_parallel:                           # DDP's constructor: rank-0 weights and buffers to everybody (two
                 ddp.broadcast_parameters(self.model)         # broadcasts of the flat buffers), before the EMA takes its copy
             self.grad_store = store
             self.flat_params = [t.requires_grad_(True) for t in self.flat.group_tensors(self.flat.flat)]
@@ -68,11 +69,11 @@ class DetectionTrainer:
             self.ema = FlatEMA(self.model, self.flat)
             self._hip_step_init()
         else:
-            if world_size > 1:
+            if self.data_parallel:
                 ddp.broadcast_parameters(self.model)
             self.optimizer = self.build_optimizer(self.model, self.args.optimizer, self.args.lr0, self.args.momentum, wd)
             self.ema = ModelEMA(self.model)
-        if world_size > 1:
+        if self.data_parallel:
             ddp.attach(self.model)
             # identical kernels on every rank: only rank 0 measures tile configurations (first eager step); its picks are
             # broadcast after the eager warm-up steps, before the graphs are captured (train_step)
@@ -261,7 +262,7 @@ class DetectionTrainer:
             history.append(rec)
             self.best_fitness = best
             stop = bool(patience and stale >= patience)
-            if self.world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            if self.data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized():
                 # only rank 0 validates, so only rank 0 knows: every rank must leave the loop together, or the others hang in
                 # the next epoch's gradient all-reduce (trainer.py:456-461 broadcasts the same flag)
                 flag = [stop]
@@ -433,7 +434,7 @@ class DetectionTrainer:
             self.optimizer_step()
             self.last_opt_step = self.ni
         self.ni += 1
-        if self.world_size > 1 and self.device.type == "cuda":
+        if self.data_parallel and self.device.type == "cuda":
             # Rank 0 alone measures tile configurations, and it measures per PROBLEM, on the first eager call that meets it:
             # the first two steps of every input signature (a new image size, the short last batch of an epoch, the first
             # steps after a resume) run eagerly and may add picks, the third is captured.  Whether THIS rank just ran such a
