@@ -250,6 +250,12 @@ int sy11_attention_fwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32
 int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
                        int32_t qkv_ld, const float* p, const void* d_o, int32_t do_ld, void* dqkv, int32_t dqkv_ld,
                        float* workspace, void* stream);
+/* the same with the forward output o (B, N, heads*hd) at hand: the per-query row sums of softmax's backward are dO . o, so the MFMA path
+ * reads P once instead of twice (o == NULL: identical to sy11_attention_bwd).  autograd's SoftmaxBackward of
+ * `attn.softmax(dim=-1)` (nn/modules/block.py:1928) — same sums, taken from the product instead of the factors.            */
+int sy11_attention_bwd_o(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
+                         int32_t qkv_ld, const float* p, const void* o, int32_t o_ld, const void* d_o, int32_t do_ld, void* dqkv,
+                         int32_t dqkv_ld, float* workspace, void* stream);
 size_t sy11_attention_workspace_bytes(int32_t B, int32_t N, int32_t heads);
 
 /* ---- Detect decode + NMS (nn/modules/head.py:100-131; utils/ops.py:181-332 + torchvision.ops.nms) ------- */

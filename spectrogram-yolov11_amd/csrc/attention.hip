@@ -611,10 +611,13 @@ __global__ __launch_bounds__(256) void attention_fwd_mma(int B, int N, int heads
 
 // backward A: wave = 32 queries.  dP^T = V dO^T per key tile (registers), delta_q = sum_j dP P (pass 1, also written
 // to ws for kernel B), dS^T = P^T (dP^T - delta); dQ^T += K^T dS^T with all of K staged [N][32] (row stride 64 B).
-template <typename T>
+// HAVE_O (r04): delta_q = sum_j dP_qj P_qj = dO_q . (sum_j P_qj V_j) = dO_q . O_q — with the forward output at hand pass 1 (every P row
+// and every dP tile a second time) is one 64-element dot product per query.
+template <typename T, bool HAVE_O = false>
 __global__ __launch_bounds__(256) void attention_bwd_q_mma(int B, int N, int heads, const T* __restrict__ qkv, int qkv_ld,
                                                            const float* __restrict__ p, const T* __restrict__ d_o, int do_ld,
-                                                           T* __restrict__ dqkv, int dqkv_ld, float* __restrict__ delta_ws, float scale) {
+                                                           T* __restrict__ dqkv, int dqkv_ld, float* __restrict__ delta_ws, float scale,
+                                                           const T* __restrict__ o_fwd, int o_ld) {
   constexpr int KD = 32, HD = 64, HC = 128, KROW = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char sK[];       // [ntile*32][64 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -656,13 +659,24 @@ __global__ __launch_bounds__(256) void attention_bwd_q_mma(int B, int N, int hea
     }
   };
   float delta = 0.f;
-  if (wave_live)
+  if constexpr (HAVE_O && sizeof(T) == 2) {        // (the f32 instantiation only keeps the dtype dispatch compiling)
+    const T* orow = o_fwd + ((long)b * N + qi) * o_ld + h * HD + 8 * half;      // the lane's half of the query's 64 outputs, as dof holds dO
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      typedef T t8 __attribute__((ext_vector_type(8)));
+      const t8 ov = *(const t8*)(orow + 16 * g);
+      const t8 dv = __builtin_bit_cast(t8, dof[g]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) delta += ElemTraits<T>::to_f(ov[i]) * ElemTraits<T>::to_f(dv[i]);
+    }
+  } else if (wave_live) {
     for (int jt = 0; jt < ntile; ++jt) {
       float dpv[16], pv[16];
       dp_tile(jt, dpv, pv);
 #pragma unroll
       for (int r = 0; r < 16; ++r) delta += dpv[r] * pv[r];
     }
+  }
   delta += __shfl_xor(delta, 32);
   if (wave_live && q_ok && half == 0) delta_ws[((long)b * heads + h) * N + qi] = delta;
   __syncthreads();                                                          // sK staged
@@ -855,9 +869,19 @@ extern "C" size_t sy11_attention_workspace_bytes(int32_t B, int32_t N, int32_t h
   return (B <= 0 || N <= 0 || heads <= 0) ? 0 : (size_t)B * heads * N * N * sizeof(float);
 }
 
+extern "C" int sy11_attention_bwd_o(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
+                                    int32_t qkv_ld, const float* p, const void* o, int32_t o_ld, const void* d_o, int32_t do_ld, void* dqkv,
+                                    int32_t dqkv_ld, float* workspace, void* stream);
 extern "C" int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
                                   int32_t qkv_ld, const float* p, const void* d_o, int32_t do_ld, void* dqkv, int32_t dqkv_ld,
                                   float* workspace, void* stream) {
+  return sy11_attention_bwd_o(dtype, B, N, heads, kd, hd, qkv, qkv_ld, p, nullptr, 0, d_o, do_ld, dqkv, dqkv_ld, workspace, stream);
+}
+
+extern "C" int sy11_attention_bwd_o(int32_t dtype, int32_t B, int32_t N, int32_t heads, int32_t kd, int32_t hd, const void* qkv,
+                                    int32_t qkv_ld, const float* p, const void* o, int32_t o_ld, const void* d_o, int32_t do_ld, void* dqkv,
+                                    int32_t dqkv_ld, float* workspace, void* stream) {
+  SY11_REQUIRE(!o || o_ld >= heads * hd, "attention_bwd: bad stride of the forward output");
   const bool use_mma = att_mma_ok(dtype, N, kd, hd, qkv, qkv_ld, d_o, do_ld) && dqkv_ld % 8 == 0 && (((uintptr_t)dqkv | (uintptr_t)p) & 15) == 0 &&
                        (size_t)cdiv(N, 32) * 32 * 64 <= 150 * 1024;
   int rc = att_check(dtype, B, N, heads, kd, hd, "attention_bwd", use_mma);
@@ -873,9 +897,14 @@ extern "C" int sy11_attention_bwd(int32_t dtype, int32_t B, int32_t N, int32_t h
     dim3 gm(cdiv(ntile, 4), heads, B);
     const size_t lq = (size_t)ntile * 32 * 64, lk = (size_t)2 * (32 * 192 + 32 * 64) + (size_t)ntile * 32 * 4;
     SY11_DISPATCH_DTYPE(dtype, T, {
-      if (lq > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_bwd_q_mma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+      if (lq > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_bwd_q_mma<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
       if (lk > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_bwd_kv_mma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lk);
-      hipLaunchKernelGGL((attention_bwd_q_mma<T>), gm, block, lq, st, B, N, heads, (const T*)qkv, qkv_ld, p, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, workspace, scale);
+      const bool have_o = o != nullptr && o_ld % 8 == 0 && ((uintptr_t)o & 15) == 0;
+      if (have_o) {
+        if (lq > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_bwd_q_mma<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+        hipLaunchKernelGGL((attention_bwd_q_mma<T, true>), gm, block, lq, st, B, N, heads, (const T*)qkv, qkv_ld, p, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, workspace, scale, (const T*)o, o_ld);
+      } else
+        hipLaunchKernelGGL((attention_bwd_q_mma<T, false>), gm, block, lq, st, B, N, heads, (const T*)qkv, qkv_ld, p, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, workspace, scale, (const T*)nullptr, 0);
       hipLaunchKernelGGL((attention_bwd_kv_mma<T>), gm, block, lk, st, B, N, heads, (const T*)qkv, qkv_ld, p, (const float*)workspace, (const T*)d_o, do_ld, (T*)dqkv, dqkv_ld, scale);
     });
     SY11_LAUNCH_CHECK("attention_bwd");

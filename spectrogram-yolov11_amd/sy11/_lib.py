@@ -81,6 +81,7 @@ SIGNATURES = {
     "sy11_bias_grad_cast": [_i32, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
     "sy11_attention_fwd": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp],
     "sy11_attention_bwd": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
+    "sy11_attention_bwd_o": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp],
     "sy11_detect_decode": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "sy11_nms_sorted": [_i32, _vp, _f32, _vp, _vp, _vp],
     "sy11_nms_sorted_batched": [_i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp],

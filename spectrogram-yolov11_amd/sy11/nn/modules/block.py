@@ -175,7 +175,7 @@ class Attention(_EngineModule):
                 # o.grad holds d(attn_out + pe(v)); attention core backward writes dq, dk, dv for all heads
                 dqkv, acc = qkv.grad_for_write()
                 assert not acc
-                ops.attention_bwd(qkv.data, nh, kd, hd, p, o.grad_read(), dqkv)
+                ops.attention_bwd(qkv.data, nh, kd, hd, p, o.grad_read(), dqkv, o=o.data)
                 gv = v.grad_read()                       # from the pe branch
                 for h in range(nh):
                     ops.copy2d(gv[..., h * hd:(h + 1) * hd], dqkv[..., h * hc + 2 * kd:(h + 1) * hc], accumulate=True)

@@ -284,12 +284,17 @@ def attention_fwd(qkv, heads, kd, hd, o, p):
     return o
 
 
-def attention_bwd(qkv, heads, kd, hd, p, d_o, dqkv, ws=None):
+def attention_bwd(qkv, heads, kd, hd, p, d_o, dqkv, ws=None, o=None):
+    """``o``: the forward output (optional) — with it the 16-bit MFMA path takes softmax's row sums as dO . o and reads P once."""
     B, H, W, _ = qkv.shape
     if ws is None:                                   # caller-owned scratch, sized by the library's own query
         ws = torch.empty(_lib.load().sy11_attention_workspace_bytes(B, H * W, heads) // 4, dtype=torch.float32, device=qkv.device)
-    call("sy11_attention_bwd", dt_code(qkv.dtype), B, H * W, heads, kd, hd, _p(qkv), view_ld(qkv), _p(p), _p(d_o),
-         view_ld(d_o), _p(dqkv), view_ld(dqkv), _p(ws), _stream())
+    if o is None:
+        call("sy11_attention_bwd", dt_code(qkv.dtype), B, H * W, heads, kd, hd, _p(qkv), view_ld(qkv), _p(p), _p(d_o),
+             view_ld(d_o), _p(dqkv), view_ld(dqkv), _p(ws), _stream())
+    else:
+        call("sy11_attention_bwd_o", dt_code(qkv.dtype), B, H * W, heads, kd, hd, _p(qkv), view_ld(qkv), _p(p), _p(o), view_ld(o), _p(d_o),
+             view_ld(d_o), _p(dqkv), view_ld(dqkv), _p(ws), _stream())
     return dqkv
 
 

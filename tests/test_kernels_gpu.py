@@ -687,6 +687,9 @@ def test_attention_fwd_bwd(B, H, W, heads, dtype):
     ws = torch.empty(B, heads, N, N, dtype=torch.float32, device=DEV)
     o.attention_bwd(qv, heads, kd, hd, p, nhwc(do, dtype), dq, ws)
     close(to_nchw(dq), qq.grad, dtype, "attention dqkv", mult=8)
+    dq2 = torch.empty_like(dq)                      # with the forward output: row sums as dO . o (the MFMA path reads P once)
+    o.attention_bwd(qv, heads, kd, hd, p, nhwc(do, dtype), dq2, ws, o=ov)
+    close(to_nchw(dq2), qq.grad, dtype, "attention dqkv (row sums from o)", mult=8)
 
 
 def test_detect_decode_matches_oracle():
