@@ -67,9 +67,10 @@ def sweep(eager):
         ns = int(os.environ.get("BN_SLOTS", "8"))
         sg, sgx = torch.zeros(ns, N, device="cuda"), torch.zeros(ns, N, device="cuda")      # 8 slots, as nn/modules/conv.py
         dgam, dbet = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
-        fns = {"fwd": (lambda: ops.bn_act_fwd(y, scale, shift, z, True), 2),
-               "reduce": (lambda: ops.bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, True, sg, sgx), 2),
-               "apply": (lambda: ops.bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, True, sg, sgx, dy, dgam, dbet), 3)}
+        act = os.environ.get("BN_SILU", "1") != "0"            # 0: the passes without the activation (how much of them is SiLU arithmetic)
+        fns = {"fwd": (lambda: ops.bn_act_fwd(y, scale, shift, z, act), 2),
+               "reduce": (lambda: ops.bn_act_bwd_reduce(y, dz, mean, rstd, scale, shift, act, sg, sgx), 2),
+               "apply": (lambda: ops.bn_act_bwd_apply(y, dz, mean, rstd, scale, shift, gamma, act, sg, sgx, dy, dgam, dbet), 3)}
         row = f"{OH:3d}x{OW:<3d}x{N:<4d} x{cnt:<2d}"
         for name, (fn, passes) in fns.items():
             ms = timed(fn, reps, eager)

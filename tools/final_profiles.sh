@@ -18,3 +18,5 @@ cp gpurun_out/prof_r4pred/bench.json gpurun_out/r7f/predict_val_bench.json
 f=$(ls gpurun_out/prof_r4pred/*kernel_stats.csv | head -1); cp "$f" gpurun_out/r7f/predict_val_kernel_stats.csv
 rm -f gpurun_out/prof_r4pred/*kernel_trace.csv
 echo all done
+timeout -k 10 200 python tools/soak.py > gpurun_out/r7f/soak_300_steps.txt 2>&1 || true
+tail -3 gpurun_out/r7f/soak_300_steps.txt
