@@ -252,3 +252,49 @@ def test_every_yaml_scale_trains_and_matches_oracle_loss(scale, n_params):
     assert abs(loss.item() - oloss.item()) <= 2e-3 * abs(oloss.item()), (scale, loss.item(), oloss.item())
     g0 = dict(m.named_parameters())["model.0.conv.weight"].grad
     assert g0 is not None and torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+
+
+@pytest.mark.parametrize("H,W,nb,nc", [(96, 160, 3, 1), (160, 96, 1, 3), (64, 224, 5, 80), (32, 32, 16, 2)])
+def test_rectangular_inputs_odd_batches_and_few_classes_vs_oracle(H, W, nb, nc):
+    """Shapes the square 64-multiple cases above never reach: rectangular inputs (the validator's `rect` batches, data/build.py:129-157),
+    batch sizes 1 / 3 / 5, class counts that are not a multiple of the 16-byte channel vector (nc = 1, 2, 3: the Detect class branch
+    pads its gradient operand), and the smallest legal input (32 x 32: a 1 x 1 stride-32 map; 16 images, because training BatchNorm over the
+    TWO values a 2-image batch leaves per channel there is +-1 by construction and amplifies last-bit differences without bound —
+    `python -m tests._layer_probe 32 32 2 2` shows the oracle and the device agree to 9e-5 up to that map and part ways behind it).
+    One fp32 train step of yolo11n against the oracle: loss 1e-3, every gradient tensor 1 % of its norm + floor."""
+    from sy11.nn.tasks import DetectionModel
+    torch.manual_seed(7)
+    m = DetectionModel("yolo11n.yaml", nc=nc, verbose=False)
+    m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    layers = R.resolve_graph("n", nc=nc)
+    sd = R.seeded_state_dict(R.empty_state_dict(layers), seed=4)
+    m.load_state_dict(sd)
+    m._sy11_dtype = torch.float32
+    m = m.to(DEV).train()
+    img = R.seeded_image((nb, 3, H, W), seed=21)
+    g = torch.Generator().manual_seed(H * 7 + W)
+    nt = nb + 1
+    bi = torch.cat([torch.arange(nb, dtype=torch.float32), torch.tensor([float(nb - 1)])])
+    batch = {"img": img.to(DEV), "batch_idx": bi.to(DEV), "cls": torch.randint(0, nc, (nt, 1), generator=g).float().to(DEV),
+             "bboxes": torch.cat([0.35 + 0.3 * torch.rand(nt, 2, generator=g), 0.2 + 0.4 * torch.rand(nt, 2, generator=g)], 1).to(DEV)}
+    loss, items = m(batch)
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k, v in osd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    maps = R.forward(osd, layers, img, train=True)
+    oloss, oitems = loss_ref.detection_loss(maps, {k: v.cpu() for k, v in batch.items()}, nc=nc)
+    assert abs(loss.item() - oloss.item()) <= 1e-3 * abs(oloss.item()), (loss.item(), oloss.item())
+    np.testing.assert_allclose(items.cpu().numpy(), oitems.numpy(), rtol=1e-3, atol=1e-5)
+    loss.backward()
+    oloss.backward()
+    params = dict(m.named_parameters())
+    gmax = max(osd[k].grad.norm().item() for k in params if osd[k].grad is not None)
+    bad = []
+    for k, p in params.items():
+        if not p.requires_grad or osd[k].grad is None:
+            continue
+        d = (p.grad.cpu() - osd[k].grad).norm().item()
+        if d > 1e-2 * osd[k].grad.norm().item() + 1e-4 * gmax:
+            bad.append((k, d, osd[k].grad.norm().item()))
+    assert not bad, bad[:8]
