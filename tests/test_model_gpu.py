@@ -298,3 +298,43 @@ def test_rectangular_inputs_odd_batches_and_few_classes_vs_oracle(H, W, nb, nc):
         if d > 1e-2 * osd[k].grad.norm().item() + 1e-4 * gmax:
             bad.append((k, d, osd[k].grad.norm().item()))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("H,W,nb,nc", [(96, 160, 3, 1), (160, 96, 1, 3), (64, 224, 5, 80), (32, 32, 16, 2)])
+def test_rectangular_inputs_in_f16_stay_near_the_f32_oracle(H, W, nb, nc):
+    """The same shapes through the 16-bit kernels (their vector forms need channel counts in multiples of 8: nc = 1, 2, 3 take the padded
+    paths; 1 x 1 and 2 x 2 maps take partial tiles everywhere).  Not a parity bar — the f16 bars live in tests/_f16_parity.py on a trained
+    state — but a sanity one: loss within 2 % of the f32 oracle's, finite gradients whose direction agrees (cosine >= 0.98)."""
+    from sy11.nn.tasks import DetectionModel
+    torch.manual_seed(7)
+    m = DetectionModel("yolo11n.yaml", nc=nc, verbose=False)
+    m.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    layers = R.resolve_graph("n", nc=nc)
+    sd = R.seeded_state_dict(R.empty_state_dict(layers), seed=4)
+    m.load_state_dict(sd)
+    m._sy11_dtype = torch.float16
+    m = m.to(DEV).train()
+    img = R.seeded_image((nb, 3, H, W), seed=21)
+    g = torch.Generator().manual_seed(H * 7 + W)
+    nt = nb + 1
+    bi = torch.cat([torch.arange(nb, dtype=torch.float32), torch.tensor([float(nb - 1)])])
+    batch = {"img": img.to(DEV), "batch_idx": bi.to(DEV), "cls": torch.randint(0, nc, (nt, 1), generator=g).float().to(DEV),
+             "bboxes": torch.cat([0.35 + 0.3 * torch.rand(nt, 2, generator=g), 0.2 + 0.4 * torch.rand(nt, 2, generator=g)], 1).to(DEV)}
+    loss, _ = m(batch)
+    loss.backward()
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k, v in osd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    maps = R.forward(osd, layers, img, train=True)
+    oloss, _ = loss_ref.detection_loss(maps, {k: v.cpu() for k, v in batch.items()}, nc=nc)
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) <= 2e-2 * abs(oloss.item()), (loss.item(), oloss.item())
+    dot = na = nb2 = 0.0
+    for k, p in m.named_parameters():
+        if not p.requires_grad or osd[k].grad is None:
+            continue
+        assert torch.isfinite(p.grad).all(), k
+        a, b = p.grad.float().cpu().flatten(), osd[k].grad.flatten()
+        dot += float(a @ b); na += float(a @ a); nb2 += float(b @ b)
+    assert dot / (na ** 0.5 * nb2 ** 0.5) >= 0.98, dot / (na ** 0.5 * nb2 ** 0.5)
