@@ -40,6 +40,8 @@ def make_case(B, nc, hw, n_gt, seed):
     (2, 80, [(16, 16), (8, 8), (4, 4)], [3, 1], 0),
     (3, 5, [(20, 12), (10, 6), (5, 3)], [4, 0, 2], 1),          # an image without targets, non-square maps
     (2, 2, [(8, 8), (4, 4), (2, 2)], [6], 2),                   # many overlapping boxes -> multi-gt conflicts
+    (2, 80, [(8, 8), (4, 4), (2, 2)], [0], 3),                  # a batch without a single target (utils/loss.py:197-198): background BCE only
+    (1, 3, [(4, 4), (2, 2), (1, 1)], [2], 4),                   # one image, 21 anchors: fewer candidates per level than topk = 10 at the coarse levels
 ])
 def test_fused_loss_matches_oracle(B, nc, hw, n_gt, seed):
     from sy11 import ops as K
@@ -64,9 +66,16 @@ def test_fused_loss_matches_oracle(B, nc, hw, n_gt, seed):
     gt = loss_ref.pack_targets(batch["batch_idx"], batch["cls"], batch["bboxes"], B, imgsz[[1, 0, 1, 0]])
     w = K.det_loss_forward([m.to(DEV).permute(0, 2, 3, 1).contiguous() for m in maps], (8., 16., 32.), nc, gt.to(DEV))
     asg = w.assign.cpu()
-    assert torch.equal(asg >= 0, fg)
-    assert torch.equal(asg[fg].long(), gt_idx[fg])
-    assert torch.allclose(w.norm.cpu(), t_scores.sum(-1), rtol=1e-4, atol=1e-6)
+    fg = fg.bool()                                  # (the oracle's mask of a target-free batch is a float zeros tensor)
+    # An anchor inside a box whose alignment metric is EXACTLY zero (no overlap with its own prediction) ties with the masked-out
+    # anchors in select_topk_candidates' torch.topk (tal.py:196-201); whether it is among the ten is the backend's tie order, and it
+    # carries weight zero either way (target score 0: no box / DFL term, background BCE).  Such anchors may differ; all others may not.
+    dev_fg, weight = asg >= 0, t_scores.sum(-1)
+    differs = dev_fg != fg
+    assert not (differs & ((weight > 0) | (w.norm.cpu() > 0))).any(), (dev_fg, fg)
+    both = dev_fg & fg
+    assert torch.equal(asg[both].long(), gt_idx[both])
+    assert torch.allclose(w.norm.cpu(), weight, rtol=1e-4, atol=1e-6)
 
 
 def test_device_labels_with_recycled_addresses_are_repacked_per_batch():
