@@ -114,3 +114,44 @@ def test_bus_jpg_predict_matches_reference_cpu_path():
     assert got.shape[0] == ref_out[0].shape[0] and got.shape[0] > 0
     assert torch.equal(got[:, 5], ref_out[0][:, 5]) and torch.equal(got[:, 4], ref_out[0][:, 4])          # class ids and scores of the kept rows
     assert res[0].orig_shape == (1080, 810)
+
+
+@pytest.mark.parametrize("case", ["empty_image", "agnostic", "max_det_5", "one_class", "single_image_max_nms", "classes_filter"])
+def test_nms_wrapper_edge_cases_match_oracle(case):
+    """non_max_suppression's device path (r04: candidate selection, one key sort, per-(image, class) bit matrices) against the restated
+    wrapper on identical inputs, kept rows bit for bit: an image without a candidate between two that have some, class-agnostic
+    suppression, a tiny max_det, a one-class model (multi_label is forced off, utils/ops.py:235), more than max_nms = 30 000
+    candidates in one image (the reference keeps the 30 000 best, ops.py:291-292), and a class filter (the tensor-op path)."""
+    from sy11.utils.ops import non_max_suppression
+    g = torch.Generator().manual_seed(11)
+    B, A, nc = (1, 8400, 12) if case == "single_image_max_nms" else (3, 1500, 1 if case == "one_class" else 7)
+    pred = torch.zeros(B, 4 + nc, A)
+    pred[:, 0:2] = 50 + 500 * torch.rand(B, 2, A, generator=g)
+    pred[:, 2:4] = 10 + 150 * torch.rand(B, 2, A, generator=g)
+    pred[:, 4:] = torch.rand(B, nc, A, generator=g) ** (1 if case == "single_image_max_nms" else 4)
+    kw = dict(conf_thres=0.05, iou_thres=0.6, multi_label=True, max_det=300)
+    if case == "empty_image":
+        pred[1, 4:] *= 0.01                                   # nothing above the threshold in the middle image
+    if case == "agnostic":
+        kw["agnostic"] = True
+    if case == "max_det_5":
+        kw["max_det"] = 5
+    if case == "single_image_max_nms":
+        kw["conf_thres"] = 0.6                                # 12 x 8400 x 0.4 = 40 000 candidate pairs > max_nms
+    ref_kw = {k: v for k, v in kw.items()}
+    if case == "classes_filter":
+        got = non_max_suppression(pred.clone().to(DEV), classes=[1, 3], **kw)
+        ref, _ = nms_ref.non_max_suppression(pred[:, [0, 1, 2, 3, 5, 7]].clone(), nc=2, **ref_kw)     # the two wanted classes alone ...
+        for r in ref:
+            r[:, 5] = torch.where(r[:, 5] == 0, 1.0, 3.0)                                             # ... under their own ids
+    else:
+        got = non_max_suppression(pred.clone().to(DEV), **kw)
+        ref, _ = nms_ref.non_max_suppression(pred.clone(), **ref_kw)
+    assert len(got) == B
+    if case == "empty_image":
+        assert got[1].shape == (0, 6)
+    if case == "single_image_max_nms":
+        assert int((pred[0, 4:] > 0.6).sum()) > 30000
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape, (a.shape, b.shape)
+        assert torch.equal(a.cpu(), b)
