@@ -782,3 +782,40 @@ def test_conv_fwd_bn_tail_matches_separate_finalize(case):
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b_ in zip(outs[0][1:], outs[1][1:]):
         assert torch.allclose(a, b_, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_fft,hop,n_frames,n_mel", [
+    (1024, 256, 37, 600),      # wave-per-frame kernel: frames not a multiple of the run (2) or of four waves x run, mel bank not a multiple of 64
+    (1024, 256, 5, 640),       # the same with one frame per wave
+    (1024, 256, 333, 512),     # runs of 5 frames, a partial last workgroup
+    (1024, 128, 300, 640),     # hop != 256: the workgroup-per-frame kernel, four frames per workgroup
+    (1024, 512, 9, 640),       # ... one frame per workgroup
+    (256, 64, 50, 160),        # other FFT sizes: the generic radix-2 kernel
+    (2048, 512, 12, 1280),
+])
+def test_stft_logmel_other_shapes_match_torch_stft(n_fft, hop, n_frames, n_mel):
+    """Every dispatch branch of sy11_stft_logmel (stft.hip) on ragged shapes against torch.stft + the oracle's filter bank on the CPU:
+    dB values, the per-image min / max the kernel reduces on the way, and the normalised image."""
+    from oracle import stft_ref as S
+    o = ops()
+    B = 3
+    L = n_fft + (n_frames - 1) * hop
+    g = torch.Generator().manual_seed(n_fft + hop + n_frames)
+    iq = torch.complex(torch.randn(B, L, generator=g), torch.randn(B, L, generator=g)) * 0.3
+    t = torch.arange(L, dtype=torch.float32)
+    iq = (iq + torch.exp(2j * math.pi * (0.11 * t + 1e-6 * t * t)).to(torch.complex64)).to(torch.complex64)      # a chirp above the noise
+    win = torch.hann_window(n_fft, periodic=True)
+    X = torch.stft(iq, n_fft, hop_length=hop, win_length=n_fft, window=win, center=False, onesided=False, return_complex=True)
+    P = torch.fft.fftshift(X, dim=1).abs() ** 2
+    ref = 10.0 * torch.log10(torch.einsum("jk,bkt->bjt", torch.from_numpy(S.mel_matrix(n_mel, n_fft)), P) + S.LOG_EPS)     # (B, mel, frames)
+    start, wts = S.mel_table(n_mel, n_fft)
+    db, mm = o.stft_logmel(iq.to(DEV), win.to(DEV), torch.from_numpy(start).to(DEV), torch.from_numpy(wts).to(DEV), n_fft, hop, n_frames, n_mel)
+    got = db.cpu().transpose(1, 2)
+    err = (got - ref).abs()
+    assert err.max().item() < 5e-2 and err.mean().item() < 2e-4, (err.max().item(), err.mean().item())
+    assert torch.allclose(mm[:, 0].cpu(), got.amin((1, 2))) and torch.allclose(mm[:, 1].cpu(), got.amax((1, 2)))
+    img = o.stft_normalize(db, mm).cpu()
+    lo, hi = ref.amin((1, 2), keepdim=True), ref.amax((1, 2), keepdim=True)
+    ref_img = ((ref - lo) / (hi - lo).clamp(min=1e-12)).unsqueeze(1).expand(-1, 3, -1, -1)
+    assert img.shape == (B, 3, n_mel, n_frames)
+    assert (img - ref_img).abs().max().item() < 2e-3
