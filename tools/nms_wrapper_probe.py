@@ -22,24 +22,26 @@ def t(fn, n=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 print("whole non_max_suppression: %.3f ms" % t(lambda: U.non_max_suppression(pred.clone(), 0.001, 0.7, multi_label=True, max_det=300)))
 print("  pred.clone(): %.3f ms" % t(lambda: pred.clone()))
-key, anchor, cidx, counts = K.nms_candidates(pred, nc, 0.001, True)
-print("  candidates (2 kernels + cumsum + host read): %.3f ms, %d candidates" % (t(lambda: K.nms_candidates(pred, nc, 0.001, True)), key.numel()))
+key, anchor, cidx, counts, by_class = K.nms_candidates(pred, nc, 0.001, True, True)
+print("  candidates (2 kernels + cumsum + host read): %.3f ms, %d candidates, per-class segments: %s" % (t(lambda: K.nms_candidates(pred, nc, 0.001, True, True)), key.numel(), by_class))
 print("  xywh2xyxy in (B,4,A): %.3f ms" % t(lambda: torch.cat((pred[:, 0:2] - pred[:, 2:4] / 2, pred[:, 0:2] + pred[:, 2:4] / 2), 1)))
 print("  sort 64-bit keys (stable): %.3f ms" % t(lambda: torch.sort(key, stable=True)))
 order = torch.sort(key, stable=True).indices
-ks = key[order]; img = ks >> 32; a_idx = anchor[order].long(); c = cidx[order].long()
+ks = key[order]; seg = ks >> 32; img = seg // nc if by_class else seg; a_idx = anchor[order].long(); c = cidx[order].long()
 print("  gathers key/anchor/class + conf: %.3f ms" % t(lambda: (key[order], anchor[order].long(), cidx[order].long(), ((~ks) & 0xFFFFFFFF).to(torch.int32).view(torch.float32))))
 xy = torch.cat((pred[:, 0:2] - pred[:, 2:4] / 2, pred[:, 0:2] + pred[:, 2:4] / 2), 1)
 print("  box gather + class shift: %.3f ms" % t(lambda: (xy[img, :, a_idx] + (c.float() * 7680).unsqueeze(1)).contiguous()))
 box = (xy[img, :, a_idx] + (c.float() * 7680).unsqueeze(1)).contiguous()
-print("  suppression kernels: %.3f ms" % t(lambda: K.nms_sorted_batched(box, counts, 0.7, 300)))
-keep = K.nms_sorted_batched(box, counts, 0.7, 300)
+print("  suppression kernels (one bit matrix per (image, class)): %.3f ms" % t(lambda: K.nms_sorted_segments(box, seg, B * nc, 0.7, 300)))
+keep = K.nms_sorted_segments(box, seg, B * nc, 0.7, 300)
 def tail():
     kept = torch.nonzero(keep, as_tuple=True)[0]
+    kept = kept[torch.sort(order[kept]).indices]
+    kept = kept[torch.sort((img[kept] << 32) | (ks[kept] & 0xFFFFFFFF), stable=True).indices]
     kimg = img[kept]
     kcount = torch.bincount(kimg, minlength=B)
     krank = torch.arange(kept.numel(), device=dev) - (torch.cumsum(kcount, 0) - kcount)[kimg]
     kept = kept[krank < 300]
     sizes = torch.bincount(img[kept], minlength=B).tolist()
     return sizes
-print("  tail (nonzero, ranks, sizes host read): %.3f ms" % t(tail))
+print("  tail (nonzero, two re-sorts of the survivors, ranks, sizes host read): %.3f ms" % t(tail))
