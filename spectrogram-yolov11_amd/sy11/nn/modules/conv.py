@@ -18,6 +18,7 @@ from ...engine import Act, Ctx, run_module
 import os
 
 _BN_TAIL = os.environ.get("SY11_BN_TAIL", "0") != "0"
+_BN_STAT_SLOTS = max(1, int(os.environ.get("SY11_BN_STAT_SLOTS", "32")))     # statistic rows per layer; r04 sweep: 4 ... 32 rows are equal within noise, 1 row costs 0.65 ms per step (profiles/r04/bn_fused_finalize_experiment.txt)
 
 __all__ = ("Conv", "DWConv", "DDWConv", "Concat", "WeightedSpatialAttention", "GCT", "Fusion", "autopad")
 
@@ -189,7 +190,7 @@ class Conv(nn.Module):
                 ops.conv2d_fwd(x.data, w, y, k, s, p, d, g)
             ops.bn_act_fwd(y, scale, shift, out.data, silu=silu, res=res.data if res is not None else None)
             return out
-        slots = 32 if B * OH * OW >= 128 * 64 else 1        # spread the per-channel stat atomics (see sy11.h)
+        slots = _BN_STAT_SLOTS if B * OH * OW >= 128 * 64 else 1        # spread the per-channel stat atomics (see sy11.h)
         st = ec.zeros(2, slots, N)
         v = torch.empty((4, N), dtype=torch.float32, device=ec.device)
         mean, rstd, scale, shift = v[0], v[1], v[2], v[3]
