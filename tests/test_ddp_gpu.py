@@ -63,3 +63,22 @@ def test_two_ranks_identical_weights(tmp_path, overlap):
     from sy11.engine import ddp
     env = dict(os.environ, OMP_NUM_THREADS="2", SY11_TUNE="1", SY11_DDP_OVERLAP=overlap)
     assert ddp.launch([str(script)], 2, env=env, timeout=600) == [0, 0]
+
+
+def test_bench_two_ranks_prints_exactly_one_json_line(tmp_path):
+    """`python3 bench.py --gpus 2` as the driver runs it, rehearsed on one GPU (both ranks on cuda:0 over gloo): the self-launching parent
+    returns 0, stdout carries EXACTLY one line and it is the JSON line of rank 0 (gloo announces every group it connects on stdout —
+    the trainer's control group included — so bench.py writes its line to the saved descriptor and points fd 1 at stderr), and rank 0's
+    own roofline leg, which runs after the other rank has left, issues no collective (r04: the per-step control all-reduce did)."""
+    import json
+    import subprocess
+    env = dict(os.environ, SY11_DDP_BACKEND="gloo", SY11_FORCE_DEVICE="0", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--imgsz", "256",
+                        "--no-stft", "--no-cpu-baseline", "--no-extras", "--no-fwd-leg"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["global_batch"] == 8
+    assert out["gradient_exchange"] is not None and out["roofline"] is not None
