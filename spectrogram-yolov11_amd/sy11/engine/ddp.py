@@ -33,6 +33,12 @@ def setup_process_group(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsing N ranks on a box with fewer GPUs: SY11_FORCE_DEVICE puts every rank on that device, SY11_DDP_BACKEND=gloo carries the
+    # collectives (RCCL refuses two ranks on one GPU) — bench.py --gpus N and YOLO(...).train(device=[...]) both come through here
+    if "SY11_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["SY11_FORCE_DEVICE"])
+    if backend is None:
+        backend = os.environ.get("SY11_DDP_BACKEND") or None
     if (world > 1 or REHEARSE) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

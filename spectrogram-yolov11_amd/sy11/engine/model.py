@@ -193,8 +193,11 @@ class YOLO:
         with tempfile.NamedTemporaryFile("w", suffix=".py", prefix="_sy11_ddp_", delete=False) as f:
             f.write(src)
         vis = ",".join(str(d) for d in devices)
+        env = {**os.environ, "HIP_VISIBLE_DEVICES": vis, "CUDA_VISIBLE_DEVICES": vis}
+        if "SY11_FORCE_DEVICE" in os.environ:                  # rehearsal of N ranks on fewer GPUs (ddp.setup_process_group): the ranks
+            env = dict(os.environ)                             # share the forced device, the visibility list is left alone
         try:
-            ddp.launch([f.name], len(devices), env={**os.environ, "HIP_VISIBLE_DEVICES": vis, "CUDA_VISIBLE_DEVICES": vis})
+            ddp.launch([f.name], len(devices), env=env)
         finally:
             os.unlink(f.name)
         best = Path(save_dir) / "best.pt"

@@ -82,3 +82,38 @@ def test_bench_two_ranks_prints_exactly_one_json_line(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["global_batch"] == 8
     assert out["gradient_exchange"] is not None and out["roofline"] is not None
+
+
+def test_front_door_train_with_a_device_list_two_ranks(tmp_path):
+    """`YOLO(cfg).train(data=yaml, device=[0, 1])` outside a launcher (engine/model.py:754-840 -> engine/trainer.py:170-207): the parent
+    spawns one child per device before it has touched the GPU, the children shard the dataset (DistributedSampler semantics), sum their
+    gradients every step, rank 0 validates and saves, the early-stop flag is broadcast, and the parent continues with best.pt and the
+    per-epoch records.  Rehearsed with both ranks on cuda:0 over gloo (SY11_FORCE_DEVICE / SY11_DDP_BACKEND, read by
+    ddp.setup_process_group); run in a fresh interpreter because the spawning parent must not have initialised the GPU."""
+    import json
+    import subprocess
+    script = tmp_path / "front_door.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        from pathlib import Path
+        sys.path.insert(0, r"{ROOT}"); sys.path.insert(0, r"{ROOT / 'spectrogram-yolov11_amd'}")
+        from tests.test_engine_flow_gpu import _dataset
+        from sy11 import YOLO
+        if __name__ == "__main__":
+            root = Path(r"{tmp_path}")
+            _dataset(root / "ds" / "train", 16, 96, 5)
+            _dataset(root / "ds" / "val", 6, 96, 6)
+            (root / "ds" / "data.yaml").write_text("path: .\\ntrain: train/images\\nval: val/images\\nnames:\\n  0: bright\\n  1: dark\\n")
+            y = YOLO("yolo11n.yaml")
+            hist = y.train(data=str(root / "ds" / "data.yaml"), epochs=2, batch=4, imgsz=96, workers=0, save_dir=str(root / "run"), close_mosaic=1,
+                           warmup_epochs=0.5, device=[0, 1])
+            print(json.dumps({{"epochs": len(hist), "names": y.model.names, "has_ckpt": y.ckpt is not None,
+                              "files": sorted(p.name for p in (root / "run").iterdir())}}, default=str))
+        """))
+    env = dict(os.environ, SY11_DDP_BACKEND="gloo", SY11_FORCE_DEVICE="0", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith("{")][-1])
+    assert out["epochs"] == 2 and out["has_ckpt"] and {"last.pt", "results.json"} <= set(out["files"])
