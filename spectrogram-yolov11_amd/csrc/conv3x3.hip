@@ -390,7 +390,7 @@ int sy11_halo3x3_launch(const IgemmArgs& a_in, int bn_code, hipStream_t st) {
   else halo_launch_tile<2>(a, bn, epi, th, tw, grid, st, tx, ty);
   SY11_LAUNCH_CHECK("halo3x3");
   if (det) {
-    return dp.fold01(a_in.stat_sum, a_in.stat_sq);
+    return dp.fold01(a_in.stat_sum, a_in.stat_sq, a_in.stat_slots, a_in.stat_stride);
   }
   return SY11_OK;
 }

@@ -280,7 +280,7 @@ int sy11_smallc3x3_launch(const IgemmArgs& a_in, int dtype, hipStream_t st) {
 #undef SY11_SCW
   SY11_LAUNCH_CHECK("smallc3x3");
   if (det) {
-    return dp.fold01(a_in.stat_sum, a_in.stat_sq);
+    return dp.fold01(a_in.stat_sum, a_in.stat_sq, a_in.stat_slots, a_in.stat_stride);
   }
   return SY11_OK;
 }

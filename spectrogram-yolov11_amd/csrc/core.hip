@@ -91,6 +91,10 @@ float* sy11_det_workspace(hipStream_t st, size_t bytes) {
   while (want < bytes) want *= 2;
   void* q = nullptr;
   if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  // the clean head (det.h): zero now, kept zero by the folds that read it.  (Not inside a capture — checked above — so a plain memset.)
+  if (hipMemset(q, 0, want < SY11_DET_CLEAN_FLOATS * sizeof(float) ? want : SY11_DET_CLEAN_FLOATS * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(q); return nullptr;
+  }
   w.p = q; w.bytes = want;                                             // the previous buffer is deliberately not freed (see above)
   return (float*)q;
 }

@@ -583,7 +583,7 @@ static int dwconv_fwd_tail(const sy11_conv_desc* d, const void* x, const void* w
     a.stat_sum = dp.buf(0); a.stat_sq = dp.buf(1); a.stat_slots = (int)rows;
     return true;
   };
-  auto det_end = [&]() -> int { return dp.fold01(stat_sum, stat_sq); };
+  auto det_end = [&]() -> int { return dp.fold01(stat_sum, stat_sq, d->stat_slots > 1 ? d->stat_slots : 1, d->C); };
   if (dw3x3_ok(d, vec)) {
     int run, rpr; unsigned g;
     dw3x3_geom(d, a.cpv, &run, &rpr, &g, 1024);               // every workgroup ends with 2*C statistic atomics
@@ -1446,7 +1446,7 @@ static int stem_fwd_tail(const sy11_conv_desc* d, const float* x_nchw, const voi
     if (!dp.acquire(st, 2, grid.x, d->N)) SY11_FAIL(SY11_ELAUNCH, "stem_conv_fwd: ordered-reduction workspace unavailable");
     a.stat_sum = dp.buf(0); a.stat_sq = dp.buf(1); a.stat_slots = (int)grid.x;
   }
-  auto det_end = [&]() -> int { return dp.fold01(stat_sum, stat_sq); };
+  auto det_end = [&]() -> int { return dp.fold01(stat_sum, stat_sq, d->stat_slots > 1 ? d->stat_slots : 1, d->N); };
   if (mma) {
     a.mag_ow = (unsigned)(((1u << 20) + d->OW - 1) / d->OW);
     a.mag_oh = (unsigned)(((1u << 20) + d->OH - 1) / d->OH);

@@ -371,7 +371,7 @@ extern "C" int sy11_bn_act_bwd_reduce(int32_t dtype, int64_t M, int32_t C, const
   });
   SY11_LAUNCH_CHECK("bn_act_bwd_reduce");
   if (det) {
-    return dp.fold01(sum_g_out, sum_gx_out);
+    return dp.fold01(sum_g_out, sum_gx_out, sum_slots > 1 ? sum_slots : 1, C);
   }
   return SY11_OK;
 }
@@ -1156,9 +1156,32 @@ extern "C" int sy11_bias_grad_cast(int32_t dtype, int64_t M, int32_t N, int32_t 
 // One stage: rows [64 * y, 64 * y + 64) of `src` -> row y of `dst` (ACCUM: added onto dst row 0 instead, used by the last stage
 // with gridDim.y == 1).  Block = 64 columns x 4 row lanes; lane q adds rows q, q + 4, ... of its 64-row group in order, the four
 // lanes are folded in index order: a fixed tree, whatever the launch timing.
+// t += src[r * stride + c] for r = r_begin, r_begin + step, ... < r_end, IN THAT ORDER — eight loads in flight per lane (the plain loop waits
+// for each load before the next: ~9 us per fold launch, r04 trace), the additions in the same order as the plain loop: same sums, bit for bit
+__device__ __forceinline__ float fold_rows_in_order(float* __restrict__ src, long stride, int c, long r_begin, long r_end, long step, int clean) {
+  float t = 0.f;
+  long r = r_begin;
+  for (; r + 7 * step < r_end; r += 8 * step) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = src[(r + i * step) * stride + c];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += v[i];
+    if (clean) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) src[(r + i * step) * stride + c] = 0.f;          // a block from the clean head of the workspace: leave zeros behind (det.h)
+    }
+  }
+  for (; r < r_end; r += step) {
+    t += src[r * stride + c];
+    if (clean) src[r * stride + c] = 0.f;
+  }
+  return t;
+}
+
 template <bool ACCUM>
-__global__ __launch_bounds__(256) void fold_stage_kernel(long rows, int N, const float* __restrict__ src, long stride, float* __restrict__ dst, long group,
-                                                         long src_bstride, long dst_bstride, float* __restrict__ dst1) {
+__global__ __launch_bounds__(256) void fold_stage_kernel(long rows, int N, float* __restrict__ src, long stride, float* __restrict__ dst, long group,
+                                                         long src_bstride, long dst_bstride, float* __restrict__ dst1, int clean) {
   // blockIdx.z = buffer (two statistic buffers of one launch fold side by side: the same tree per buffer as two separate folds)
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -1166,9 +1189,7 @@ __global__ __launch_bounds__(256) void fold_stage_kernel(long rows, int N, const
   const long r0 = (long)blockIdx.y * group, r1 = r0 + group < rows ? r0 + group : rows;
   src += (long)blockIdx.z * src_bstride;
   float* out = ACCUM ? (blockIdx.z ? dst1 : dst) : dst + (long)blockIdx.z * dst_bstride;
-  float t = 0.f;
-  if (c < N)
-    for (long r = r0 + q; r < r1; r += 4) t += src[r * stride + c];
+  const float t = c < N ? fold_rows_in_order(src, stride, c, r0 + q, r1, 4, clean) : 0.f;
   red[q][cl] = t;
   __syncthreads();
   if (q == 0 && c < N) {
@@ -1176,37 +1197,64 @@ __global__ __launch_bounds__(256) void fold_stage_kernel(long rows, int N, const
     if (ACCUM) out[c] += tot; else out[(long)blockIdx.y * N + c] = tot;
   }
 }
+// Partial rows into the caller's SLOT rows (the consumer folds those): workgroup (column block, slot s, buffer) adds rows s, s + S, ... —
+// lane q takes every fourth of them in ascending order, the four lanes are folded in index order: a fixed tree, one plain launch.
+__global__ __launch_bounds__(256) void fold_slots_kernel(long rows, int N, float* __restrict__ src, long stride, long src_bstride, int S, long slot_stride,
+                                                         float* __restrict__ out0, float* __restrict__ out1, int clean) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long s0 = blockIdx.y;
+  src += (long)blockIdx.z * src_bstride;
+  const float t = c < N ? fold_rows_in_order(src, stride, c, s0 + (long)S * q, rows, 4L * S, clean) : 0.f;
+  red[q][cl] = t;
+  __syncthreads();
+  if (q == 0 && c < N) {
+    float* out = (blockIdx.z ? out1 : out0) + s0 * slot_stride;
+    out[c] += ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+  }
+}
+int sy11_fold_rows_to_slots2(long rows, int N, float* partials, long stride, long buf_stride, int slots, long slot_stride, float* out0, float* out1,
+                             hipStream_t st, bool clean) {
+  if (rows <= 0 || N <= 0 || slots <= 0) return SY11_OK;
+  hipLaunchKernelGGL(fold_slots_kernel, dim3(cdiv(N, 64), (unsigned)slots, 2), dim3(256), 0, st, rows, N, partials, stride, buf_stride, slots, slot_stride, out0, out1, clean ? 1 : 0);
+  SY11_LAUNCH_CHECK("fold_rows_to_slots");
+  return SY11_OK;
+}
+
 // the two buffers of a DetPartials block ([2][rows][N], `scratch` twice sy11_fold_scratch_floats) in one launch per stage
-int sy11_fold_rows_ordered2(long rows, int N, const float* partials, long stride, long buf_stride, float* out0, float* out1, float* scratch,
-                            hipStream_t st) {
+int sy11_fold_rows_ordered2(long rows, int N, float* partials, long stride, long buf_stride, float* out0, float* out1, float* scratch,
+                            hipStream_t st, bool clean) {
   if (rows <= 0 || N <= 0) return SY11_OK;
-  const float* src = partials;
+  float* src = partials;
+  int cl = clean ? 1 : 0;                                 // only the first stage reads the partial block itself
   long sstride = stride, sb = buf_stride;
   float* ping = scratch;
   while (rows > 256) {
     const long nr = (rows + 63) / 64;
     float* dst = ping;
-    hipLaunchKernelGGL((fold_stage_kernel<false>), dim3(cdiv(N, 64), (unsigned)nr, 2), dim3(256), 0, st, rows, N, src, sstride, dst, 64L, sb, nr * N, (float*)nullptr);
-    src = dst; sstride = N; sb = nr * N; rows = nr;
+    hipLaunchKernelGGL((fold_stage_kernel<false>), dim3(cdiv(N, 64), (unsigned)nr, 2), dim3(256), 0, st, rows, N, src, sstride, dst, 64L, sb, nr * N, (float*)nullptr, cl);
+    src = dst; sstride = N; sb = nr * N; rows = nr; cl = 0;
     ping = dst + 2 * nr * N;
   }
-  hipLaunchKernelGGL((fold_stage_kernel<true>), dim3(cdiv(N, 64), 1, 2), dim3(256), 0, st, rows, N, src, sstride, out0, rows, sb, 0L, out1);
+  hipLaunchKernelGGL((fold_stage_kernel<true>), dim3(cdiv(N, 64), 1, 2), dim3(256), 0, st, rows, N, src, sstride, out0, rows, sb, 0L, out1, cl);
   SY11_LAUNCH_CHECK("fold_rows2");
   return SY11_OK;
 }
-int sy11_fold_rows_ordered(long rows, int N, const float* partials, long stride, float* out, float* scratch, hipStream_t st) {
+int sy11_fold_rows_ordered(long rows, int N, float* partials, long stride, float* out, float* scratch, hipStream_t st, bool clean) {
   if (rows <= 0 || N <= 0) return SY11_OK;
-  const float* src = partials;
+  float* src = partials;
+  int cl = clean ? 1 : 0;
   long sstride = stride;
   float* ping = scratch;
   while (rows > 256) {                                   // 64 rows -> 1 per stage until one workgroup column can finish
     const long nr = (rows + 63) / 64;
     float* dst = ping;
-    hipLaunchKernelGGL((fold_stage_kernel<false>), dim3(cdiv(N, 64), (unsigned)nr), dim3(256), 0, st, rows, N, src, sstride, dst, 64L, 0L, 0L, (float*)nullptr);
-    src = dst; sstride = N; rows = nr;
+    hipLaunchKernelGGL((fold_stage_kernel<false>), dim3(cdiv(N, 64), (unsigned)nr), dim3(256), 0, st, rows, N, src, sstride, dst, 64L, 0L, 0L, (float*)nullptr, cl);
+    src = dst; sstride = N; rows = nr; cl = 0;
     ping = dst + nr * N;                                 // next stage writes behind this one (scratch holds rows/64 + 64 rows)
   }
-  hipLaunchKernelGGL((fold_stage_kernel<true>), dim3(cdiv(N, 64), 1), dim3(256), 0, st, rows, N, src, sstride, out, rows, 0L, 0L, (float*)nullptr);
+  hipLaunchKernelGGL((fold_stage_kernel<true>), dim3(cdiv(N, 64), 1), dim3(256), 0, st, rows, N, src, sstride, out, rows, 0L, 0L, (float*)nullptr, cl);
   SY11_LAUNCH_CHECK("fold_rows");
   return SY11_OK;
 }

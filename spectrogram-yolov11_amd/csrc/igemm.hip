@@ -594,6 +594,7 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
   DetPartials dp;
   float* const stat_sum_out = a.stat_sum;
   float* const stat_sq_out = a.stat_sq;
+  const int stat_slots_out = a.stat_slots, stat_stride_out = a.stat_stride;
   const bool det = a.stat_sum && sy11_det(1) && !a.tail.ticket;
   if (det) {
     if (!dp.acquire(st, 2, nwg, a.N)) SY11_FAIL(SY11_ELAUNCH, "igemm: ordered-reduction workspace unavailable (%ld x %d floats)", nwg, a.N);
@@ -644,7 +645,7 @@ static int launch_cfg(IgemmArgs a, hipStream_t st, int cfg) {
 #undef SY11_IG
   SY11_LAUNCH_CHECK("igemm");
   if (det) {
-    return dp.fold01(stat_sum_out, stat_sq_out);
+    return dp.fold01(stat_sum_out, stat_sq_out, stat_slots_out, stat_stride_out);
   }
   return SY11_OK;
 }

@@ -267,7 +267,7 @@ int sy11_igemm1x1p_launch(int dtype, const void* x, const void* w, void* y, floa
 #undef SY11_P1
   SY11_LAUNCH_CHECK("igemm1x1p");
   if (det) {
-    return dp.fold01(stat_sum, stat_sq);
+    return dp.fold01(stat_sum, stat_sq, stat_slots > 1 ? stat_slots : 1, stat_stride);
   }
   return SY11_OK;
 }
