@@ -105,7 +105,7 @@ def test_front_door_train_with_a_device_list_two_ranks(tmp_path):
             _dataset(root / "ds" / "val", 6, 96, 6)
             (root / "ds" / "data.yaml").write_text("path: .\\ntrain: train/images\\nval: val/images\\nnames:\\n  0: bright\\n  1: dark\\n")
             y = YOLO("yolo11n.yaml")
-            hist = y.train(data=str(root / "ds" / "data.yaml"), epochs=2, batch=4, imgsz=96, workers=0, save_dir=str(root / "run"), close_mosaic=1,
+            hist = y.train(data=str(root / "ds" / "data.yaml"), epochs=2, batch=4, imgsz=96, workers=2, save_dir=str(root / "run"), close_mosaic=1,
                            warmup_epochs=0.5, device=[0, 1])
             print(json.dumps({{"epochs": len(hist), "names": y.model.names, "has_ckpt": y.ckpt is not None,
                               "files": sorted(p.name for p in (root / "run").iterdir())}}, default=str))
