@@ -1,3 +1,5 @@
+# Everything profiles/<round>/ is regenerated from at the last kernel commit: the full -m gpu suite, one-queue and two-queue kernel traces,
+# PMC traffic, the predict / val leg, a 300-step soak and the ordered-mode trace -> gpurun_out/r7f/ (copy what is to be judged into profiles/).
 set -e
 mkdir -p gpurun_out/r7f
 timeout -k 10 900 python -m pytest tests -q -m gpu -x > gpurun_out/r7f/gpu_suite.txt 2>&1 || { tail -30 gpurun_out/r7f/gpu_suite.txt; exit 1; }
@@ -20,3 +22,6 @@ rm -f gpurun_out/prof_r4pred/*kernel_trace.csv
 echo all done
 timeout -k 10 200 python tools/soak.py > gpurun_out/r7f/soak_300_steps.txt 2>&1 || true
 tail -3 gpurun_out/r7f/soak_300_steps.txt
+SY11_DETERMINISTIC=1 SY11_WGRAD_STREAM=0 bash tools/prof_bench.sh stats r4det > /dev/null
+python tools/trace_summary.py gpurun_out/prof_r4det/run_kernel_trace.csv gpurun_out/r7f/z_ordered 5 | tail -8
+rm -f gpurun_out/prof_r4det/run_kernel_trace.csv
